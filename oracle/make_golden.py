@@ -1,0 +1,248 @@
+"""Generate ``tests/golden/*.pt`` by executing the REFERENCE's own source
+(``/root/reference/adapter/attention_processor.py`` and ``adapter/resampler.py``, imported
+verbatim through ``oracle/ref_loader.py``) on seeded fp32 inputs (TEST INFRASTRUCTURE).
+
+Run in the build container only:   python -m oracle.make_golden
+The fixtures pin ``oracle/processors.py`` and ``oracle/resampler.py`` (tests/test_oracle_golden.py)
+and are what the ``-m gpu`` parity tests compare the HIP path with when /root/reference is absent.
+
+Two kinds of cases:
+  * "full":   small dims; inputs, weights and reference outputs are all stored.
+  * "seeded": real SD1.5 dims (d = 40/80/160, T = 77+4, Resampler 257x1280 -> 16x768); only seeds,
+              input digests and reference outputs are stored; tests regenerate inputs with
+              ``oracle.seeds.seeded``.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from .ref_loader import load_reference_adapter
+from .seeds import digest, seeded
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+class FakeAttention(nn.Module):
+    """The attribute surface the reference processors read (attention_processor.py:545-625)."""
+
+    def __init__(self, c, kdim, heads):
+        super().__init__()
+        self.heads = heads
+        self.to_q = nn.Linear(c, c, bias=False)
+        self.to_k = nn.Linear(kdim, c, bias=False)
+        self.to_v = nn.Linear(kdim, c, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
+        self.spatial_norm = None
+        self.group_norm = None
+        self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+
+    def prepare_attention_mask(self, m, *a, **k):
+        return m
+
+
+def attn_weights(seed, c, kdim):
+    s = c ** -0.5
+    return dict(
+        wq=seeded(seed + 1, c, c, scale=s), wk=seeded(seed + 2, c, kdim, scale=kdim ** -0.5),
+        wv=seeded(seed + 3, c, kdim, scale=kdim ** -0.5), wo=seeded(seed + 4, c, c, scale=s),
+        bo=seeded(seed + 5, c, scale=0.1),
+    )
+
+
+def make_attn(w, c, kdim, heads):
+    a = FakeAttention(c, kdim, heads)
+    with torch.no_grad():
+        a.to_q.weight.copy_(w["wq"]); a.to_k.weight.copy_(w["wk"]); a.to_v.weight.copy_(w["wv"])
+        a.to_out[0].weight.copy_(w["wo"]); a.to_out[0].bias.copy_(w["bo"])
+    return a
+
+
+def lora_weights(seed, c, kdim, rank):
+    # up is zero-initialised in diffusers; use non-zero values so the LoRA path is exercised
+    out = {}
+    for i, (nm, cin) in enumerate((("q", c), ("k", kdim), ("v", kdim), ("out", c))):
+        out[nm] = (seeded(seed + 10 + 2 * i, rank, cin, scale=cin ** -0.5),
+                   seeded(seed + 11 + 2 * i, c, rank, scale=rank ** -0.5))
+    return out
+
+
+def set_lora(proc, lw):
+    with torch.no_grad():
+        for nm in ("q", "k", "v", "out"):
+            layer = getattr(proc, f"to_{nm}_lora")
+            layer.down.weight.copy_(lw[nm][0]); layer.up.weight.copy_(lw[nm][1])
+
+
+@torch.no_grad()
+def hybrid_case(ap, seed, B, N, M, C, heads, scale, rank=0, lora_scale=0.0, store_full=True):
+    w = attn_weights(seed, C, C)
+    attn = make_attn(w, C, C, heads)
+    x = seeded(seed + 20, B, N, C)
+    ref = seeded(seed + 21, 1, M, C)
+    wkr, wvr = seeded(seed + 22, C, C, scale=C ** -0.5), seeded(seed + 23, C, C, scale=C ** -0.5)
+    name = "blk.attn1.processor"
+    if rank:
+        proc = ap.LoraRefSAttnProcessor2_0(name, C, rank=rank, lora_scale=lora_scale, scale=scale)
+        lw = lora_weights(seed, C, C, rank)
+        set_lora(proc, lw)
+    else:
+        proc = ap.RefSAttnProcessor2_0(name, C, scale=scale)
+        lw = None
+    proc.to_k_ref.weight.copy_(wkr); proc.to_v_ref.weight.copy_(wvr)
+    # the reference is only defined for B == 1 with a 1-batch garment (:602-603): run per sample
+    cond = torch.cat([proc(attn, x[b:b + 1], sa_hidden_states={name: ref}) for b in range(B)])
+    uncond = torch.cat([proc(attn, x[b:b + 1]) for b in range(B)])
+    case = dict(kind="hybrid", seed=seed, B=B, N=N, M=M, C=C, heads=heads, scale=scale, rank=rank,
+                lora_scale=lora_scale, out_cond=cond, out_uncond=uncond,
+                digests=dict(x=digest(x), ref=digest(ref), wq=digest(w["wq"]), wkr=digest(wkr)))
+    if store_full:
+        case.update(x=x, ref=ref, wk_ref=wkr, wv_ref=wvr, lora=lw, **w)
+    return case
+
+
+@torch.no_grad()
+def cross_case(ap, seed, B, N, T, C, KD, heads, ip_tokens=0, ip_scale=1.0, rank=0, lora_scale=0.0, store_full=True):
+    w = attn_weights(seed, C, KD)
+    attn = make_attn(w, C, KD, heads)
+    x = seeded(seed + 20, B, N, C)
+    ehs = seeded(seed + 21, B, T + ip_tokens, KD, scale=0.5)
+    case = dict(kind="cross", seed=seed, B=B, N=N, T=T, C=C, KD=KD, heads=heads, ip_tokens=ip_tokens,
+                ip_scale=ip_scale, rank=rank, lora_scale=lora_scale,
+                digests=dict(x=digest(x), ehs=digest(ehs), wq=digest(w["wq"])))
+    lw = wkip = wvip = None
+    if ip_tokens:
+        proc = ap.LoRAIPAttnProcessor2_0(C, KD, rank=rank, lora_scale=lora_scale, scale=ip_scale, num_tokens=ip_tokens)
+        lw = lora_weights(seed, C, KD, rank)
+        set_lora(proc, lw)
+        wkip, wvip = seeded(seed + 30, C, KD, scale=KD ** -0.5), seeded(seed + 31, C, KD, scale=KD ** -0.5)
+        proc.to_k_ip.weight.copy_(wkip); proc.to_v_ip.weight.copy_(wvip)
+        out = proc(attn, x, encoder_hidden_states=ehs)
+    else:
+        proc = ap.CAttnProcessor2_0("blk.attn2.processor", C, KD)
+        out = proc(attn, x, encoder_hidden_states=ehs, sa_hidden_states={"unused": None})
+    case["out"] = out
+    if store_full:
+        case.update(x=x, ehs=ehs, lora=lw, wk_ip=wkip, wv_ip=wvip, **w)
+    return case
+
+
+@torch.no_grad()
+def cache_case(ap, seed, B, N, C, heads):
+    w = attn_weights(seed, C, C)
+    attn = make_attn(w, C, C, heads)
+    x = seeded(seed + 20, B, N, C)
+    proc = ap.CacheAttnProcessor2_0()
+    out = proc(attn, x)
+    assert proc.cache["hidden_states"] is x            # stores its input (:34)
+    return dict(kind="cache", seed=seed, B=B, N=N, C=C, heads=heads, x=x, out=out, **w)
+
+
+def resampler_sd(seed, dim, depth, dim_head, heads, nq, emb, out, ff_mult=4, prefix=""):
+    inner = dim_head * heads
+    sd = {}
+    k = [seed]
+
+    def nxt():
+        k[0] += 1
+        return k[0]
+
+    def lin(name, o, i, bias):
+        sd[prefix + name + ".weight"] = seeded(nxt(), o, i, scale=i ** -0.5)
+        if bias:
+            sd[prefix + name + ".bias"] = seeded(nxt(), o, scale=0.05)
+
+    def ln(name, d):
+        sd[prefix + name + ".weight"] = 1.0 + seeded(nxt(), d, scale=0.1)
+        sd[prefix + name + ".bias"] = seeded(nxt(), d, scale=0.05)
+
+    if nq:
+        sd[prefix + "latents"] = seeded(nxt(), 1, nq, dim, scale=dim ** -0.5)
+    lin("proj_in", dim, emb, True)
+    lin("proj_out", out, dim, True)
+    ln("norm_out", out)
+    for i in range(depth):
+        p = f"layers.{i}.0"
+        ln(p + ".norm1", dim); ln(p + ".norm2", dim)
+        lin(p + ".to_q", inner, dim, False); lin(p + ".to_kv", 2 * inner, dim, False); lin(p + ".to_out", dim, inner, False)
+        f = f"layers.{i}.1"
+        ln(f + ".0", dim); lin(f + ".1", dim * ff_mult, dim, False); lin(f + ".3", dim, dim * ff_mult, False)
+    return sd
+
+
+@torch.no_grad()
+def resampler_case(rs, seed, B, L, cfg, store_full):
+    sd = resampler_sd(seed, cfg["dim"], cfg["depth"], cfg["dim_head"], cfg["heads"], cfg["num_queries"],
+                      cfg["embedding_dim"], cfg["output_dim"])
+    m = rs.Resampler(**cfg)
+    m.load_state_dict(sd, strict=True)
+    x = seeded(seed + 1000, B, L, cfg["embedding_dim"], scale=0.5)
+    out = m(x)
+    case = dict(kind="resampler", seed=seed, B=B, L=L, cfg=cfg, out=out, digests=dict(x=digest(x), latents=digest(sd["latents"])))
+    if store_full:
+        case.update(x=x, sd=sd)
+    return case
+
+
+def proj_plus_sd(seed, cad=768, idd=512, clipd=1280, ntok=4):
+    sd = resampler_sd(seed, cad, 4, 64, cad // 64, 0, clipd, cad, prefix="perceiver_resampler.")
+    sd["proj.0.weight"] = seeded(seed + 501, idd * 2, idd, scale=idd ** -0.5)
+    sd["proj.0.bias"] = seeded(seed + 502, idd * 2, scale=0.05)
+    sd["proj.2.weight"] = seeded(seed + 503, cad * ntok, idd * 2, scale=(idd * 2) ** -0.5)
+    sd["proj.2.bias"] = seeded(seed + 504, cad * ntok, scale=0.05)
+    sd["norm.weight"] = 1.0 + seeded(seed + 505, cad, scale=0.1)
+    sd["norm.bias"] = seeded(seed + 506, cad, scale=0.05)
+    return sd
+
+
+@torch.no_grad()
+def proj_plus_case(rs, seed):
+    sd = proj_plus_sd(seed)
+    m = rs.ProjPlusModel()
+    m.load_state_dict(sd, strict=True)
+    idv = seeded(seed + 2000, 1, 512)
+    clip = seeded(seed + 2001, 1, 257, 1280, scale=0.5)
+    out = m(idv, clip)                                   # default shortcut=False (..._ipa_controlnet.py:375)
+    out_sc = m(idv, clip, shortcut=True, scale=0.7)
+    return dict(kind="proj_plus", seed=seed, out=out, out_shortcut=out_sc, digests=dict(id=digest(idv), clip=digest(clip)))
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ap, rs = load_reference_adapter()
+    os.makedirs(OUT, exist_ok=True)
+    proc_cases = {
+        # full (small) cases
+        "hybrid_small": hybrid_case(ap, 100, B=2, N=48, M=80, C=64, heads=8, scale=0.9),
+        "hybrid_small_lora": hybrid_case(ap, 200, B=1, N=40, M=24, C=64, heads=8, scale=1.0, rank=16, lora_scale=0.2),
+        "cross_small": cross_case(ap, 300, B=2, N=48, T=77, C=64, KD=96, heads=8),
+        "cross_small_ip": cross_case(ap, 400, B=2, N=48, T=77, C=64, KD=96, heads=8, ip_tokens=4, ip_scale=0.9, rank=16, lora_scale=0.2),
+        "cache_small": cache_case(ap, 500, B=2, N=32, C=64, heads=8),
+        # seeded (real SD1.5 head dims; ragged N/M that are not multiples of any tile)
+        "hybrid_d40": hybrid_case(ap, 1000, B=2, N=200, M=330, C=320, heads=8, scale=1.0, store_full=False),
+        "hybrid_d80": hybrid_case(ap, 1100, B=1, N=144, M=100, C=640, heads=8, scale=0.8, store_full=False),
+        "hybrid_d160": hybrid_case(ap, 1200, B=1, N=64, M=80, C=1280, heads=8, scale=1.0, store_full=False),
+        "hybrid_d40_lora": hybrid_case(ap, 1300, B=1, N=96, M=128, C=320, heads=8, scale=0.9, rank=128, lora_scale=0.2, store_full=False),
+        "cross_d40": cross_case(ap, 1400, B=2, N=130, T=77, C=320, KD=768, heads=8, store_full=False),
+        "cross_d160_ip": cross_case(ap, 1500, B=1, N=64, T=77, C=1280, KD=768, heads=8, ip_tokens=4, ip_scale=0.9, rank=128, lora_scale=0.2, store_full=False),
+    }
+    torch.save(proc_cases, os.path.join(OUT, "processors.pt"))
+    small_cfg = dict(dim=64, depth=2, dim_head=16, heads=4, num_queries=4, embedding_dim=48, output_dim=32, ff_mult=4)
+    real_cfg = dict(dim=768, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=768, ff_mult=4)
+    res_cases = {
+        "resampler_small": resampler_case(rs, 3000, B=2, L=19, cfg=small_cfg, store_full=True),
+        "resampler_real": resampler_case(rs, 4000, B=2, L=257, cfg=real_cfg, store_full=False),   # inference_IMAGdressing.py:55-64
+        "proj_plus_real": proj_plus_case(rs, 5000),
+    }
+    torch.save(res_cases, os.path.join(OUT, "resampler.pt"))
+    for f in ("processors.pt", "resampler.pt"):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
