@@ -1,0 +1,119 @@
+"""ctypes binding of ``libimagdressing_hip.so`` (C ABI in ``include/imagdressing_hip.h``).
+
+There is exactly one backend.  Importing this module never needs a GPU, but every compute call
+does: a missing library or a non-gfx950 device raises -- nothing falls back to torch or the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimagdressing_hip.so")
+
+u16p = C.POINTER(C.c_uint16)
+f32p = C.POINTER(C.c_float)
+
+
+class HeadsDest(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("kind", C.c_int), ("DP", C.c_int), ("L", C.c_int), ("scale", C.c_float)]
+
+
+class ConvGemmParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("Cin", C.c_int), ("taps", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int),
+        ("Wout", C.c_int), ("stride", C.c_int), ("ups", C.c_int),
+        ("x_pix_stride", C.c_int), ("out_ld", C.c_int), ("res_ld", C.c_int),
+        ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_stride", C.c_int),
+        ("res", C.c_void_p), ("out_scale", C.c_float), ("act", C.c_int), ("out_f32", C.c_int),
+        ("mode", C.c_int), ("hC", C.c_int), ("hH", C.c_int), ("hD", C.c_int),
+        ("hd", HeadsDest * 3),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k1", C.c_void_p), ("v1t", C.c_void_p), ("k2", C.c_void_p), ("v2t", C.c_void_p),
+        ("scale2", C.c_void_p), ("out", C.c_void_p),
+        ("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("D", C.c_int),
+        ("L1", C.c_int), ("L1P", C.c_int), ("kv1_bdiv", C.c_int),
+        ("L2", C.c_int), ("L2P", C.c_int), ("kv2_bdiv", C.c_int),
+        ("out_ld", C.c_int),
+    ]
+
+
+class GroupNormParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partial", C.c_void_p),
+        ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("G", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int),
+        ("eps", C.c_float), ("silu", C.c_int),
+    ]
+
+
+class LayerNormParams(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("rows", C.c_int), ("C", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int), ("eps", C.c_float),
+    ]
+
+
+class DdimParams(C.Structure):
+    _fields_ = [
+        ("z", C.c_void_p), ("eps", C.c_void_p), ("x_next", C.c_void_p),
+        ("B", C.c_int), ("HW", C.c_int),
+        ("guidance", C.c_float), ("sqrt_a_t", C.c_float), ("sqrt_1m_a_t", C.c_float),
+        ("sqrt_a_prev", C.c_float), ("sqrt_1m_a_prev", C.c_float),
+        ("mask", C.c_void_p), ("z_img", C.c_void_p), ("noise", C.c_void_p),
+        ("sqrt_a_next", C.c_float), ("sqrt_1m_a_next", C.c_float),
+    ]
+
+
+# every symbol include/imagdressing_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "imd_abi_version": (C.c_int, []),
+    "imd_last_error": (C.c_char_p, []),
+    "imd_device_check": (C.c_int, [C.c_int]),
+    "imd_conv_gemm": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int, C.c_void_p]),
+    "imd_conv_gemm_auto_cfg": (C.c_int, [C.c_int, C.c_int]),
+    "imd_attention": (C.c_int, [C.POINTER(AttnParams), C.c_void_p]),
+    "imd_attn_padded_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "imd_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p]),
+    "imd_groupnorm_workspace_floats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "imd_layernorm": (C.c_int, [C.POINTER(LayerNormParams), C.c_void_p]),
+    "imd_ddim_cfg_step": (C.c_int, [C.POINTER(DdimParams), C.c_void_p]),
+    "imd_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "imd_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float, C.c_void_p]),
+    "imd_copy2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
+    "imd_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+}
+
+_lib = None
+
+
+class ImdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built -- no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImdError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or imagdressing_amd/csrc/build.sh).  imagdressing_amd has no CPU / torch fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
+            fn.restype, fn.argtypes = res, args
+        if lib.imd_abi_version() != 1:
+            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 1")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise ImdError(load().imd_last_error().decode("utf-8", "replace"))

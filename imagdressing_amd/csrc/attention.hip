@@ -1,0 +1,316 @@
+// Fused dual-softmax ("hybrid") attention for gfx950: bf16 MFMA, fp32 online softmax.
+//
+//   O[b, q, h*D:(h+1)*D] = softmax(Q K1^T) V1  +  s2[b] * softmax(Q K2^T) V2
+//
+// which is the core of the reference's hybrid processor
+// (/root/reference/adapter/attention_processor.py:589-612, RefSAttnProcessor2_0: frozen self
+// attention over the image tokens, PLUS an independently normalised cross attention over the
+// garment UNet's tokens, summed before the out-projection), and -- with K2/V2 = the 4 IP-Adapter
+// face tokens -- of LoRAIPAttnProcessor2_0 (:833-856).  With k2 == nullptr or s2[b] == 0 it is the
+// plain attention of the uncond pass / CAttnProcessor2_0 / the Perceiver resampler
+// (adapter/resampler.py:71-74; its softmax is fp32 there as it is here).
+//
+// Layouts (produced by the head-split epilogue of conv_gemm.hip):
+//   Q   [B , H, N , DPK]   already multiplied by  D^-1/2 * log2(e)   (softmax runs on exp2)
+//   K   [Bk, H, L , DPK]   rows = keys, zero padded from D to DPK (multiple of 16)
+//   V^T [Bk, H, DPV, LP]   rows = head-dim, keys contiguous, LP = L rounded up to 64 (zero padded)
+// The kv batch entry used by batch b is b / kv_bdiv (stride-0 style sharing: the garment K/V are
+// computed ONCE per garment and shared by every image of the batch; text K/V once per prompt).
+//
+// Structure: one workgroup = 4 waves = 4*QW blocks of 32 query rows of one (batch, head);
+// K / V^T tiles of 64 keys are staged global -> registers -> LDS (double buffered, one barrier
+// per tile).  Per 32x32 block the wave computes S^T = K Q^T with the MFMA rows *permuted*
+// (swap23) so that each lane ends up holding, for ITS query column, 8 consecutive keys per
+// register octet: after exp2 and bf16 packing those registers ARE the B-operand of the
+// O^T += V^T P^T MFMA -- no LDS round trip, no cross-lane shuffles for P.  Softmax statistics
+// (running max m, running sum l) are per-lane scalars because a lane owns one query column in
+// both MFMAs; the two half-waves that share a query exchange one value per tile (max) and one
+// per phase (sum).
+#include "common.h"
+#include "imd_kernels.h"
+
+namespace {
+
+constexpr int KT = 64;                 // keys per tile
+constexpr int VSTR = KT * 2 + 16;      // bytes per V^T LDS row (9 x 16 B: conflict-free b128 reads)
+
+template <int D> struct AttnCfg {
+    static constexpr int DPK = (D + 15) / 16 * 16;
+    static constexpr int DPV = (D + 31) / 32 * 32;
+    static constexpr int NKT = DPK / 16;
+    static constexpr int NDT = DPV / 32;
+    static constexpr int KSTR = DPK * 2 + 16;
+    static constexpr int BUF = KT * KSTR + DPV * VSTR;
+    static constexpr int KVECS = (KT * (DPK / 8) + 255) / 256;
+    static constexpr int VVECS = (D * (KT / 8) + 255) / 256;
+};
+
+template <int D, int QW, int MINW>
+__global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
+    using C = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int col = lane & 31;
+    const int h = blockIdx.y;
+    const int b = blockIdx.z;
+    const int q0 = (blockIdx.x * 4 + wave) * (QW * 32);
+
+    // zero the V^T pad rows (head-dim D..DPV-1) of both LDS buffers once; they are never restaged
+    if (C::DPV > D) {
+        constexpr int PADV = (C::DPV - D) * (VSTR / 16);
+        for (int v = tid; v < 2 * PADV; v += 256) {
+            const int bufi = v / PADV, r = v % PADV;
+            *reinterpret_cast<uint4*>(smem + bufi * C::BUF + KT * C::KSTR + D * VSTR + r * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    // ---- Q fragments (B operand of S^T = K Q^T): lane = query column, 8 head-dim values ----
+    uint4 qf[QW][C::NKT];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        const int q = q0 + qb * 32 + col;
+#pragma unroll
+        for (int t = 0; t < C::NKT; ++t) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.N) v = *reinterpret_cast<const uint4*>(p.q + ((size_t)(b * p.H + h) * p.N + q) * C::DPK + t * 16 + hi * 8);
+            qf[qb][t] = v;
+        }
+    }
+
+    float w2 = 0.f;
+    if (p.k2 != nullptr && p.scale2 != nullptr) w2 = p.scale2[b];
+    const int nph = (w2 != 0.f) ? 2 : 1;
+
+    f32x16 o[QW][C::NDT];
+    uint32_t o1[QW][C::NDT][8];       // phase-1 result, normalised, packed bf16 (the reference
+                                      // rounds each SDPA output to half precision before the add)
+    float m_run[QW], l_run[QW];
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o1[qb][dt][r] = 0u;
+        }
+    }
+
+    for (int ph = 0; ph < nph; ++ph) {
+        const int L = ph ? p.L2 : p.L1;
+        const int LP = ph ? p.L2P : p.L1P;
+        const int kvb = ph ? (b / p.kv2_bdiv) : (b / p.kv1_bdiv);
+        const bf16_t* kbase = (ph ? p.k2 : p.k1) + (size_t)(kvb * p.H + h) * L * C::DPK;
+        const bf16_t* vbase = (ph ? p.v2t : p.v1t) + (size_t)(kvb * p.H + h) * C::DPV * LP;
+        const int ntiles = (L + KT - 1) / KT;
+
+        uint4 kreg[C::KVECS], vreg[C::VVECS];
+        auto load_tile = [&](int t) {
+            const int kt0 = t * KT;
+#pragma unroll
+            for (int i = 0; i < C::KVECS; ++i) {
+                const int v = tid + i * 256;
+                const int row = v / (C::DPK / 8), vc = v % (C::DPK / 8);
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (v < KT * (C::DPK / 8) && kt0 + row < L)
+                    x = *reinterpret_cast<const uint4*>(kbase + (size_t)(kt0 + row) * C::DPK + vc * 8);
+                kreg[i] = x;
+            }
+#pragma unroll
+            for (int i = 0; i < C::VVECS; ++i) {
+                const int v = tid + i * 256;
+                const int row = v / (KT / 8), vc = v % (KT / 8);
+                uint4 x = make_uint4(0, 0, 0, 0);
+                if (v < D * (KT / 8))
+                    x = *reinterpret_cast<const uint4*>(vbase + (size_t)row * LP + kt0 + vc * 8);
+                vreg[i] = x;
+            }
+        };
+        auto store_tile = [&](int bufi) {
+            char* Ks = smem + bufi * C::BUF;
+            char* Vs = Ks + KT * C::KSTR;
+#pragma unroll
+            for (int i = 0; i < C::KVECS; ++i) {
+                const int v = tid + i * 256;
+                const int row = v / (C::DPK / 8), vc = v % (C::DPK / 8);
+                if (v < KT * (C::DPK / 8)) *reinterpret_cast<uint4*>(Ks + row * C::KSTR + vc * 16) = kreg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < C::VVECS; ++i) {
+                const int v = tid + i * 256;
+                const int row = v / (KT / 8), vc = v % (KT / 8);
+                if (v < D * (KT / 8)) *reinterpret_cast<uint4*>(Vs + row * VSTR + vc * 16) = vreg[i];
+            }
+        };
+
+        load_tile(0);
+        store_tile(0);
+        __syncthreads();
+
+        const int kfrag = swap23(col) * C::KSTR + hi * 16;   // permuted key row of this lane
+        const int vfrag = col * VSTR + hi * 16;
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) load_tile(t + 1);
+            const char* Ks = smem + (t & 1) * C::BUF;
+            const char* Vs = Ks + KT * C::KSTR;
+            const bool ragged = (t + 1) * KT > L;
+#pragma unroll
+            for (int qb = 0; qb < QW; ++qb) {
+                // ---- S^T = K Q^T for the two 32-key blocks of the tile ----
+                f32x16 s[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+                    for (int tk = 0; tk < C::NKT; ++tk) {
+                        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kb * 32 * C::KSTR + kfrag + tk * 32);
+                        s[kb] = mfma32(kf, qf[qb][tk], s[kb]);
+                    }
+                }
+                if (ragged) {     // keys >= L of the last tile contribute nothing
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = t * KT + kb * 32 + 8 * hi + (r & 7) + 16 * (r >> 3);
+                            if (key >= L) s[kb][r] = -INFINITY;
+                        }
+                }
+                // ---- online softmax (base 2; Q carries the scale) ----
+                float mx = s[0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float m_new = fmaxf(m_run[qb], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                m_run[qb] = m_new;
+                float psum = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float pe = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
+                        s[kb][r] = pe;
+                        psum += pe;
+                    }
+                l_run[qb] = l_run[qb] * alpha + psum;
+#pragma unroll
+                for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+                // ---- P^T fragments: register octet g of block kb = keys 16g+8hi..+7 of that block ----
+                uint4 pf[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kb = g >> 1, r0 = (g & 1) * 8;
+                    pf[g].x = pack_bf2(s[kb][r0 + 0], s[kb][r0 + 1]);
+                    pf[g].y = pack_bf2(s[kb][r0 + 2], s[kb][r0 + 3]);
+                    pf[g].z = pack_bf2(s[kb][r0 + 4], s[kb][r0 + 5]);
+                    pf[g].w = pack_bf2(s[kb][r0 + 6], s[kb][r0 + 7]);
+                }
+                // ---- O^T += V^T P^T ----
+#pragma unroll
+                for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + g * 32);
+                        o[qb][dt] = mfma32(vf, pf[g], o[qb][dt]);
+                    }
+            }
+            if (t + 1 < ntiles) store_tile((t + 1) & 1);
+            __syncthreads();
+        }
+
+        // ---- end of phase: normalise; stash phase 1 when a second phase follows ----
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) {
+            const float lt = l_run[qb] + __shfl_xor(l_run[qb], 32);
+            const float inv = 1.0f / lt;
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][dt][r] *= inv;
+            if (ph == 0 && nph == 2) {
+#pragma unroll
+                for (int dt = 0; dt < C::NDT; ++dt) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) o1[qb][dt][r] = pack_bf2(o[qb][dt][2 * r], o[qb][dt][2 * r + 1]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
+                }
+                m_run[qb] = -INFINITY;
+                l_run[qb] = 0.f;
+            }
+        }
+    }
+
+    // ---- epilogue: O = O1 + w2 * O2 (or O1 alone); lane owns query q, 4 consecutive head-dims / quad
+    const float wgt = (nph == 2) ? w2 : 1.0f;
+#pragma unroll
+    for (int qb = 0; qb < QW; ++qb) {
+        const int q = q0 + qb * 32 + col;
+        if (q >= p.N) continue;
+        bf16_t* orow = p.out + ((size_t)b * p.N + q) * p.out_ld + h * D;
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dd = dt * 32 + 8 * j + 4 * hi;
+                if (dd >= D) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * j + e;
+                    const uint32_t w = o1[qb][dt][r >> 1];
+                    const float first = (r & 1) ? bf_hi(w) : bf_lo(w);
+                    v[e] = first + wgt * o[qb][dt][r];
+                }
+                *reinterpret_cast<uint2*>(orow + dd) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+            }
+    }
+}
+
+template <int D, int QW, int MINW>
+int launch_attn(const AttnParams& p, hipStream_t s) {
+    using C = AttnCfg<D>;
+    constexpr int lds = 2 * C::BUF;
+    static bool attr_set = false;
+    auto kern = attn_kernel<D, QW, MINW>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return imd_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int rows = 4 * QW * 32;
+    dim3 grid((p.N + rows - 1) / rows, p.H, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return imd_check_launch("attention");
+}
+
+}  // namespace
+
+int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
+int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }
+
+int imd_launch_attention(const AttnParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.H <= 0 || p.N <= 0 || p.L1 <= 0) return imd_set_error("attention: empty problem B=%d H=%d N=%d L1=%d", p.B, p.H, p.N, p.L1);
+    if (p.L1P % 64 || p.L1P < p.L1) return imd_set_error("attention: L1P (%d) must be a multiple of 64 and >= L1 (%d)", p.L1P, p.L1);
+    if (p.k2 && (p.L2 <= 0 || p.L2P % 64 || p.L2P < p.L2)) return imd_set_error("attention: bad second key set L2=%d L2P=%d", p.L2, p.L2P);
+    if (p.kv1_bdiv <= 0 || (p.k2 && p.kv2_bdiv <= 0)) return imd_set_error("attention: kv batch divisors must be positive");
+    if (p.H > 65535 || p.B > 65535) return imd_set_error("attention: H/B exceed grid limits");
+    switch (p.D) {
+        case 40: return (p.N >= 1024) ? launch_attn<40, 2, 2>(p, s) : launch_attn<40, 1, 2>(p, s);
+        case 64: return launch_attn<64, 1, 2>(p, s);
+        case 80: return launch_attn<80, 1, 2>(p, s);
+        case 160: return launch_attn<160, 1, 1>(p, s);
+        default: return imd_set_error("attention: unsupported head dim %d (supported: 40, 64, 80, 160)", p.D);
+    }
+}

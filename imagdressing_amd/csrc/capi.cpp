@@ -1,0 +1,112 @@
+// C-ABI entry points of libimagdressing_hip.so (see include/imagdressing_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "imd_kernels.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int imd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+int imd_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return imd_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+#define IMD_REQUIRE(cond, ...) do { if (!(cond)) return imd_set_error(__VA_ARGS__); } while (0)
+
+extern "C" {
+
+int imd_abi_version(void) { return IMD_ABI_VERSION; }
+const char* imd_last_error(void) { return g_err; }
+
+int imd_device_check(int device) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return imd_set_error("device_check: hipGetDeviceProperties(%d) failed: %s", device, hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return imd_set_error("device_check: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return 0;
+}
+
+int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream) {
+    IMD_REQUIRE(p != nullptr, "conv_gemm: null params");
+    IMD_REQUIRE(p->x && p->w, "conv_gemm: null input/weight pointer");
+    IMD_REQUIRE(p->mode == IMD_OUT_HEADS || p->out != nullptr, "conv_gemm: null output pointer");
+    IMD_REQUIRE(p->Hout > 0 && p->Wout > 0 && p->Hin > 0 && p->Win > 0, "conv_gemm: bad geometry");
+    IMD_REQUIRE(p->stride == 1 || p->stride == 2, "conv_gemm: stride must be 1 or 2");
+    IMD_REQUIRE(p->M % (p->Hout * p->Wout) == 0, "conv_gemm: M (%d) is not a multiple of Hout*Wout (%d)", p->M, p->Hout * p->Wout);
+    if (p->mode == IMD_OUT_HEADS) {
+        IMD_REQUIRE(p->hC > 0 && p->hH > 0 && p->hD > 0 && p->hC == p->hH * p->hD, "conv_gemm: bad head split C=%d H=%d D=%d", p->hC, p->hH, p->hD);
+        IMD_REQUIRE(p->N % p->hC == 0 && p->N / p->hC <= 3, "conv_gemm: N (%d) must be 1..3 splits of %d channels", p->N, p->hC);
+        IMD_REQUIRE(p->hD % 4 == 0, "conv_gemm: head dim must be a multiple of 4");
+        IMD_REQUIRE(p->act != IMD_ACT_GEGLU && !p->out_f32, "conv_gemm: head-split output excludes GEGLU / fp32 output");
+    }
+    if (p->act == IMD_ACT_GEGLU) IMD_REQUIRE(!p->out_f32 && !p->res, "conv_gemm: GEGLU excludes fp32 output and residual");
+    return imd_launch_conv_gemm(*p, cfg, (hipStream_t)stream);
+}
+
+int imd_conv_gemm_auto_cfg(int M, int N) { return imd_conv_gemm_choose_cfg(M, N); }
+
+int imd_attention(const imd_attn_params* p, void* stream) {
+    IMD_REQUIRE(p != nullptr, "attention: null params");
+    IMD_REQUIRE(p->q && p->k1 && p->v1t && p->out, "attention: null q/k/v/out pointer");
+    IMD_REQUIRE((p->k2 == nullptr) == (p->v2t == nullptr), "attention: k2 and v2t must be given together");
+    IMD_REQUIRE(p->out_ld >= p->H * p->D && p->out_ld % 4 == 0, "attention: bad out_ld %d", p->out_ld);
+    return imd_launch_attention(*p, (hipStream_t)stream);
+}
+
+int imd_attn_padded_dims(int D, int* dpk, int* dpv) {
+    IMD_REQUIRE(D == 40 || D == 64 || D == 80 || D == 160, "attn_padded_dims: unsupported head dim %d", D);
+    if (dpk) *dpk = imd_attn_dpk(D);
+    if (dpv) *dpv = imd_attn_dpv(D);
+    return 0;
+}
+
+int imd_groupnorm(const imd_groupnorm_params* p, void* stream) {
+    IMD_REQUIRE(p && p->x && p->y && p->gamma && p->beta && p->partial, "groupnorm: null pointer");
+    return imd_launch_groupnorm(*p, (hipStream_t)stream);
+}
+
+int imd_layernorm(const imd_layernorm_params* p, void* stream) {
+    IMD_REQUIRE(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
+    return imd_launch_layernorm(*p, (hipStream_t)stream);
+}
+
+int imd_ddim_cfg_step(const imd_ddim_params* p, void* stream) {
+    IMD_REQUIRE(p && p->z && p->eps, "ddim_cfg_step: null pointer");
+    IMD_REQUIRE(p->sqrt_a_t > 0.f, "ddim_cfg_step: sqrt(alpha_t) must be positive");
+    return imd_launch_ddim_cfg_step(*p, (hipStream_t)stream);
+}
+
+int imd_timestep_embedding(const float* t, float* out, int B, int dim, void* stream) {
+    IMD_REQUIRE(t && out, "timestep_embedding: null pointer");
+    return imd_launch_timestep_embedding(t, out, B, dim, (hipStream_t)stream);
+}
+
+int imd_add(const uint16_t* a, int a_ld, const uint16_t* b, int b_ld, uint16_t* out, int out_ld, long rows, int C, float b_scale, void* stream) {
+    IMD_REQUIRE(a && b && out, "add: null pointer");
+    return imd_launch_add(a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale, (hipStream_t)stream);
+}
+
+int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows, int C, void* stream) {
+    IMD_REQUIRE(a && out, "copy2d: null pointer");
+    return imd_launch_copy2d(a, a_ld, out, out_ld, rows, C, (hipStream_t)stream);
+}
+
+int imd_f32_to_bf16(const float* a, uint16_t* out, long n, void* stream) {
+    IMD_REQUIRE(a && out, "f32_to_bf16: null pointer");
+    return imd_launch_f32_to_bf16(a, out, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,141 @@
+// HBM-bound elementwise kernels of the sampling loop (gfx950).
+//
+// ddim_cfg_step fuses, over the [B, HW, 4] latent:
+//   classifier-free guidance      eps = eps_u + g (eps_c - eps_u)
+//       (/root/reference/dressing_sd/pipelines/IMAGDressing_v1_pipeline.py:521-527)
+//   the DDIM update (eta = 0)     x0 = (z - sqrt(1-a_t) eps) / sqrt(a_t);  z' = sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+//       (diffusers==0.24.0 DDIMScheduler.step, call site :530-532)
+//   the inpainting blend          z' = (1-m) add_noise(z_img, noise, t_next) + m z'
+//       (..._pipeline_controlnet_inpainting.py:487-500)
+//   and the next step's UNet input: bf16, channels padded 4 -> 8, duplicated for the cond and
+//   uncond halves (torch.cat([latents]*2), :483-488; scale_model_input is the identity for DDIM).
+// Algorithmic traffic per latent element: 3 fp32 reads + 1 fp32 write (+3 reads with inpaint)
+// + 2 x 4 B of bf16 next-input writes.
+#include "common.h"
+#include "imd_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void ddim_cfg_step_kernel(const DdimParams p) {
+    const long total = (long)p.B * p.HW;                   // one thread per pixel (4 channels = 16 B)
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const float4 z = reinterpret_cast<const float4*>(p.z)[i];
+        const float4 ec = reinterpret_cast<const float4*>(p.eps)[i];
+        const float4 eu = reinterpret_cast<const float4*>(p.eps)[i + total];
+        float zz[4] = {z.x, z.y, z.z, z.w};
+        const float c[4] = {ec.x, ec.y, ec.z, ec.w};
+        const float u[4] = {eu.x, eu.y, eu.z, eu.w};
+        float mk = 1.f;
+        float zi[4] = {0, 0, 0, 0}, nz[4] = {0, 0, 0, 0};
+        if (p.mask) {
+            mk = p.mask[i];
+            const float4 a = reinterpret_cast<const float4*>(p.z_img)[i];
+            const float4 n = reinterpret_cast<const float4*>(p.noise)[i];
+            zi[0] = a.x; zi[1] = a.y; zi[2] = a.z; zi[3] = a.w;
+            nz[0] = n.x; nz[1] = n.y; nz[2] = n.z; nz[3] = n.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float eps = u[e] + p.guidance * (c[e] - u[e]);
+            const float x0 = (zz[e] - p.sqrt_1m_a_t * eps) / p.sqrt_a_t;
+            float zn = p.sqrt_a_prev * x0 + p.sqrt_1m_a_prev * eps;
+            if (p.mask) {
+                const float proper = p.sqrt_a_next * zi[e] + p.sqrt_1m_a_next * nz[e];
+                zn = (1.f - mk) * proper + mk * zn;
+            }
+            zz[e] = zn;
+        }
+        reinterpret_cast<float4*>(p.z)[i] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+        if (p.x_next) {
+            const uint4 o = make_uint4(pack_bf2(zz[0], zz[1]), pack_bf2(zz[2], zz[3]), 0u, 0u);
+            reinterpret_cast<uint4*>(p.x_next)[i] = o;
+            reinterpret_cast<uint4*>(p.x_next)[i + total] = o;
+        }
+    }
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ void timestep_embedding_kernel(const float* t, float* out, int B, int dim) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i - b * half;
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);   // ln(10000)
+    const float arg = t[b] * freq;
+    out[(size_t)b * dim + j] = cosf(arg);
+    out[(size_t)b * dim + half + j] = sinf(arg);
+}
+
+// out[r, c] = a[r, c] + b_scale * b[r, c]   (strided rows; 8 channels per thread)
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld,
+                                                   long rows, int C, float b_scale) {
+    const int vpr = C / 8;
+    const long total = rows * vpr;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long r = i / vpr;
+        const int c = (int)(i - r * vpr) * 8;
+        float fa[8], fb[8];
+        unpack8(*reinterpret_cast<const uint4*>(a + r * a_ld + c), fa);
+        unpack8(*reinterpret_cast<const uint4*>(b + r * b_ld + c), fb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] += b_scale * fb[e];
+        *reinterpret_cast<uint4*>(out + r * out_ld + c) = pack8(fa);
+    }
+}
+
+__global__ __launch_bounds__(256) void copy2d_kernel(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C) {
+    const int vpr = C / 8;
+    const long total = rows * vpr;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long r = i / vpr;
+        const int c = (int)(i - r * vpr) * 8;
+        *reinterpret_cast<uint4*>(out + r * out_ld + c) = *reinterpret_cast<const uint4*>(a + r * a_ld + c);
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* a, bf16_t* out, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = f2bf(a[i]);
+}
+
+inline unsigned grid_for(long work_items) {
+    long blocks = (work_items + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.HW <= 0) return imd_set_error("ddim_cfg_step: empty latent");
+    if (p.mask && (!p.z_img || !p.noise)) return imd_set_error("ddim_cfg_step: inpaint mask given without image latents / noise");
+    hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3(grid_for((long)p.B * p.HW)), dim3(256), 0, s, p);
+    return imd_check_launch("ddim_cfg_step");
+}
+
+int imd_launch_timestep_embedding(const float* t, float* out, int B, int dim, hipStream_t s) {
+    if (B <= 0 || dim <= 0 || (dim & 1)) return imd_set_error("timestep_embedding: bad shape B=%d dim=%d", B, dim);
+    const int n = B * dim / 2;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, out, B, dim);
+    return imd_check_launch("timestep_embedding");
+}
+
+int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, hipStream_t s) {
+    if (rows <= 0 || C <= 0) return imd_set_error("add: empty tensor");
+    if (C % 8 || a_ld % 8 || b_ld % 8 || out_ld % 8) return imd_set_error("add: C and row strides must be multiples of 8");
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale);
+    return imd_check_launch("add");
+}
+
+int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C, hipStream_t s) {
+    if (rows <= 0 || C <= 0) return imd_set_error("copy2d: empty tensor");
+    if (C % 8 || a_ld % 8 || out_ld % 8) return imd_set_error("copy2d: C and row strides must be multiples of 8");
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, a, a_ld, out, out_ld, rows, C);
+    return imd_check_launch("copy2d");
+}
+
+int imd_launch_f32_to_bf16(const float* a, bf16_t* out, long n, hipStream_t s) {
+    if (n <= 0) return imd_set_error("f32_to_bf16: empty tensor");
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, out, n);
+    return imd_check_launch("f32_to_bf16");
+}

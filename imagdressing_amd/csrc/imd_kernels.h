@@ -1,0 +1,35 @@
+// Internal (C++) interface between the C-ABI layer (capi.cpp) and the HIP kernels.
+// The parameter structs ARE the public C structs of include/imagdressing_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/imagdressing_hip.h"
+
+typedef uint16_t bf16_t;
+typedef imd_heads_dest HeadsDest;
+typedef imd_conv_gemm_params ConvGemmParams;
+typedef imd_attn_params AttnParams;
+typedef imd_groupnorm_params GroupNormParams;
+typedef imd_layernorm_params LayerNormParams;
+typedef imd_ddim_params DdimParams;
+
+enum { ACT_NONE = IMD_ACT_NONE, ACT_SILU = IMD_ACT_SILU, ACT_GEGLU = IMD_ACT_GEGLU };
+enum { OUT_ROWMAJOR = IMD_OUT_ROWMAJOR, OUT_HEADS = IMD_OUT_HEADS };
+
+// error plumbing (thread-local message, surfaced by imd_last_error())
+int imd_set_error(const char* fmt, ...);
+int imd_check_launch(const char* what);
+
+int imd_conv_gemm_choose_cfg(int M, int N);
+int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
+int imd_launch_attention(const AttnParams& p, hipStream_t s);
+int imd_attn_dpk(int D);
+int imd_attn_dpv(int D);
+int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s);
+int imd_launch_layernorm(const LayerNormParams& p, hipStream_t s);
+int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s);
+int imd_launch_timestep_embedding(const float* t, float* out, int B, int dim, hipStream_t s);
+int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, hipStream_t s);
+int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C, hipStream_t s);
+int imd_launch_f32_to_bf16(const float* a, bf16_t* out, long n, hipStream_t s);

@@ -1,0 +1,209 @@
+// GroupNorm(+SiLU) and LayerNorm for NHWC / token-major bf16 activations (HBM-bound kernels).
+//
+// Reference arithmetic (diffusers==0.24.0, un-vendored): ResnetBlock2D norm1/norm2 + SiLU,
+// Transformer2DModel.norm (eps 1e-6, no activation), conv_norm_out + SiLU; BasicTransformerBlock
+// norm1/2/3 and the LayerNorms of /root/reference/adapter/resampler.py:16,43-44,199.
+//
+// GroupNorm runs as two launches over the same tensor: (1) per-(batch, pixel-chunk, group)
+// fp32 partial sums -- every thread owns a FIXED 8-channel vector column so its accumulators stay
+// in registers and all loads are 16-byte coalesced -- written to a small workspace (deterministic,
+// no atomics); (2) normalise + affine (+ SiLU), each block first folding the partials of its batch
+// entry.  Statistics are fp32.
+#include "common.h"
+#include "imd_kernels.h"
+
+namespace {
+
+constexpr int GN_THREADS = 320;          // 5 waves: divides evenly for C/8 = 40, 80, 160, 320
+constexpr int GN_PIX_PER_CHUNK = 64;
+
+__device__ __forceinline__ int gn_chunks(int HW) { return (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK; }
+
+// One thread: vector column `vec` (channels 8*vec .. 8*vec+7), pixel lanes interleaved.
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormParams p) {
+    __shared__ float red[GN_THREADS][4];
+    const int vpp = p.C / 8;                       // vectors per pixel
+    const int tid = threadIdx.x;
+    const int cpg = p.C / p.G;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int pix0 = chunk * GN_PIX_PER_CHUNK;
+    const int pix1 = min(p.HW, pix0 + GN_PIX_PER_CHUNK);
+    const int nchunks = gn_chunks(p.HW);
+
+    // columns are processed in passes of GN_THREADS / ppb ... keep it simple: loop over
+    // column blocks of width `cols` = min(vpp, GN_THREADS); pixel lanes = GN_THREADS / cols.
+    const int cols = min(vpp, GN_THREADS);
+    const int plan = GN_THREADS / cols;            // pixel lanes
+    const int my_col = tid % cols, my_pl = tid / cols;
+    const bool active = my_pl < plan;
+
+    for (int cbase = 0; cbase < vpp; cbase += cols) {
+        const int vec = cbase + my_col;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        const int c0 = vec * 8;
+        const int g0 = c0 / cpg;
+        const int split = min(8, (g0 + 1) * cpg - c0);   // channels [0,split) -> g0, rest -> g0+1
+        if (active && vec < vpp) {
+            for (int pix = pix0 + my_pl; pix < pix1; pix += plan) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p.x + ((size_t)b * p.HW + pix) * p.x_ld + c0);
+                float f[8];
+                unpack8(v, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
+                    else           { s1 += f[e]; q1 += f[e] * f[e]; }
+                }
+            }
+        }
+        red[tid][0] = s0; red[tid][1] = q0; red[tid][2] = s1; red[tid][3] = q1;
+        __syncthreads();
+        // thread g (< G) folds every (pixel lane, column) entry that touches group g
+        if (tid < p.G) {
+            const int g = tid;
+            const int cfirst = g * cpg, clast = (g + 1) * cpg - 1;
+            int vlo = cfirst / 8, vhi = clast / 8;
+            vlo = max(vlo, cbase); vhi = min(vhi, min(vpp, cbase + cols) - 1);
+            float S = 0.f, Q = 0.f;
+            for (int v = vlo; v <= vhi; ++v) {
+                const int vg0 = (v * 8) / cpg;
+                for (int pl = 0; pl < plan; ++pl) {
+                    const float* e = red[pl * cols + (v - cbase)];
+                    if (vg0 == g) { S += e[0]; Q += e[1]; }
+                    else if (vg0 + 1 == g) { S += e[2]; Q += e[3]; }
+                }
+            }
+            float* dst = p.partial + (((size_t)b * nchunks + chunk) * p.G + g) * 2;
+            if (cbase == 0) { dst[0] = S; dst[1] = Q; }
+            else { dst[0] += S; dst[1] += Q; }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormParams p) {
+    __shared__ float s_mean[64], s_rstd[64];
+    const int vpp = p.C / 8;
+    const int tid = threadIdx.x;
+    const int cpg = p.C / p.G;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int nchunks = gn_chunks(p.HW);
+    if (tid < p.G) {
+        float S = 0.f, Q = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            const float* src = p.partial + (((size_t)b * nchunks + c) * p.G + tid) * 2;
+            S += src[0]; Q += src[1];
+        }
+        const float n = (float)p.HW * (float)cpg;
+        const float mean = S / n;
+        const float var = fmaxf(Q / n - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    const int pix0 = chunk * GN_PIX_PER_CHUNK;
+    const int pix1 = min(p.HW, pix0 + GN_PIX_PER_CHUNK);
+    const int cols = min(vpp, GN_THREADS);
+    const int plan = GN_THREADS / cols;
+    const int my_col = tid % cols, my_pl = tid / cols;
+    if (my_pl >= plan) return;
+    for (int cbase = 0; cbase < vpp; cbase += cols) {
+        const int vec = cbase + my_col;
+        if (vec >= vpp) continue;
+        const int c0 = vec * 8;
+        float a[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c0 + e) / cpg;
+            const float ga = p.gamma[c0 + e] * s_rstd[g];
+            a[e] = ga;
+            sh[e] = p.beta[c0 + e] - s_mean[g] * ga;
+        }
+        for (int pix = pix0 + my_pl; pix < pix1; pix += plan) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p.x + ((size_t)b * p.HW + pix) * p.x_ld + c0);
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = f[e] * a[e] + sh[e];
+                if (p.silu) y = silu_f(y);
+                f[e] = y;
+            }
+            *reinterpret_cast<uint4*>(p.y + ((size_t)b * p.HW + pix) * p.y_ld + c0) = pack8(f);
+        }
+    }
+}
+
+// One wave per row; C <= 8 * 64 * LN_MAXV.
+constexpr int LN_MAXV = 4;
+__global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nv = p.C / 8;
+    float f[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int v = lane + i * 64;
+        if (v < nv) {
+            const uint4 x = *reinterpret_cast<const uint4*>(p.x + (size_t)row * p.x_ld + v * 8);
+            unpack8(x, f[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += f[i][e];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)p.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int v = lane + i * 64;
+        if (v < nv) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; q += d * d; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q / (float)p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int v = lane + i * 64;
+        if (v < nv) {
+            float y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) y[e] = (f[i][e] - mean) * rstd * p.gamma[v * 8 + e] + p.beta[v * 8 + e];
+            *reinterpret_cast<uint4*>(p.y + (size_t)row * p.y_ld + v * 8) = pack8(y);
+        }
+    }
+}
+
+}  // namespace
+
+int imd_groupnorm_workspace_floats(int B, int HW, int C, int G) {
+    (void)C;
+    return B * ((HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK) * G * 2;
+}
+
+int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
+    if (p.B <= 0 || p.HW <= 0 || p.C <= 0) return imd_set_error("groupnorm: empty tensor");
+    if (p.C % 8 || p.C % p.G || p.G > 64) return imd_set_error("groupnorm: C (%d) must be a multiple of 8 and of G (%d <= 64)", p.C, p.G);
+    if ((p.C / p.G) < 8) return imd_set_error("groupnorm: channels per group (%d) must be >= 8", p.C / p.G);
+    if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("groupnorm: pixel strides must be multiples of 8");
+    const int chunks = (p.HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK;
+    dim3 grid(chunks, p.B);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, s, p);
+    int rc = imd_check_launch("groupnorm stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, s, p);
+    return imd_check_launch("groupnorm apply");
+}
+
+int imd_launch_layernorm(const LayerNormParams& p, hipStream_t s) {
+    if (p.rows <= 0) return imd_set_error("layernorm: no rows");
+    if (p.C % 8 || p.C > 8 * 64 * LN_MAXV) return imd_set_error("layernorm: C (%d) must be a multiple of 8 and <= %d", p.C, 8 * 64 * LN_MAXV);
+    if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("layernorm: row strides must be multiples of 8");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    return imd_check_launch("layernorm");
+}

@@ -1,0 +1,265 @@
+"""Typed wrappers around the C ABI that take torch tensors as *device memory handles* only
+(``data_ptr()`` + the current HIP stream).  No torch math happens here; CPU tensors, wrong dtypes
+and non-contiguous views raise -- there is no eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+bf16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype, name: str) -> int:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise L.ImdError(f"{name}: tensor is on {t.device}; imagdressing_amd runs on MI355X only (no CPU path)")
+    if t.dtype != dtype:
+        raise L.ImdError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise L.ImdError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], dtype, name: str) -> Optional[int]:
+    return None if t is None else _dev(t, dtype, name)
+
+
+_checked_devices = set()
+
+
+def ensure_device(device: torch.device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _checked_devices:
+        L.check(L.load().imd_device_check(idx))
+        _checked_devices.add(idx)
+
+
+# ---------------------------------------------------------------------------------------------
+# persistent zero-initialised workspaces (attention Q/K/V^T buffers rely on their padding staying 0)
+# ---------------------------------------------------------------------------------------------
+_ws: Dict[Tuple, torch.Tensor] = {}
+
+
+def workspace(tag: str, shape: Sequence[int], dtype, device) -> torch.Tensor:
+    key = (tag, tuple(shape), dtype, str(device))
+    t = _ws.get(key)
+    if t is None:
+        t = torch.zeros(tuple(shape), dtype=dtype, device=device)
+        _ws[key] = t
+    return t
+
+
+def clear_workspaces():
+    _ws.clear()
+
+
+def attn_padded_dims(D: int) -> Tuple[int, int]:
+    a, b = C.c_int(), C.c_int()
+    L.check(L.load().imd_attn_padded_dims(D, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def pad64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+# ---------------------------------------------------------------------------------------------
+def conv_gemm(
+    x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, Cin: int, taps: int = 1,
+    Hin: int = 1, Win: int = 1, Hout: int = 1, Wout: int = 1, stride: int = 1, ups: bool = False,
+    x_pix_stride: Optional[int] = None, out: Optional[torch.Tensor] = None, out_ld: Optional[int] = None,
+    bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rowvec_stride: int = 0,
+    rowvec_off: int = 0, res: Optional[torch.Tensor] = None, res_ld: Optional[int] = None, out_scale: float = 1.0,
+    act: int = ACT_NONE, out_f32: bool = False,
+    heads: Optional[dict] = None, cfg: int = -1,
+) -> Optional[torch.Tensor]:
+    """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
+
+    ``heads`` = dict(C=, H=, D=, dests=[(tensor|None, kind, DP, L, scale), ...]) selects the head-split
+    epilogue (no ``out``).  Returns the output tensor (allocated when ``out`` is None).
+    """
+    ensure_device(x.device)
+    K = taps * Cin
+    p = L.ConvGemmParams()
+    p.x = _dev(x, bf16, "x")
+    p.w = _dev(w, bf16, "w")
+    if w.numel() != N * K:
+        raise L.ImdError(f"conv_gemm: weight has {w.numel()} elements, expected N*K = {N}*{K}")
+    p.M, p.N, p.K = M, N, K
+    p.Cin, p.taps, p.Hin, p.Win, p.Hout, p.Wout, p.stride, p.ups = Cin, taps, Hin, Win, Hout, Wout, stride, int(ups)
+    p.x_pix_stride = Cin if x_pix_stride is None else x_pix_stride
+    p.bias = _opt(bias, torch.float32, "bias")
+    p.rowvec = _opt(rowvec, torch.float32, "rowvec")
+    if rowvec is not None and rowvec_off:
+        if rowvec_off % 4:
+            raise L.ImdError("conv_gemm: rowvec_off must be a multiple of 4")
+        p.rowvec = p.rowvec + 4 * rowvec_off
+    p.rowvec_stride = rowvec_stride
+    p.res = _opt(res, bf16, "res")
+    p.res_ld = (N if res_ld is None else res_ld)
+    p.out_scale = out_scale
+    p.act = act
+    p.out_f32 = int(out_f32)
+    if heads is not None:
+        p.mode = 1
+        p.hC, p.hH, p.hD = heads["C"], heads["H"], heads["D"]
+        for i, (t, kind, DP, Ltok, scale) in enumerate(heads["dests"]):
+            p.hd[i].ptr = None if t is None else _dev(t, bf16, f"heads[{i}]")
+            p.hd[i].kind, p.hd[i].DP, p.hd[i].L, p.hd[i].scale = kind, DP, Ltok, scale
+        p.out = None
+        p.out_ld = 0
+    else:
+        p.mode = 0
+        n_out = N // 2 if act == ACT_GEGLU else N
+        if out is None:
+            out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else bf16, device=x.device)
+        p.out = _dev(out, torch.float32 if out_f32 else bf16, "out")
+        p.out_ld = n_out if out_ld is None else out_ld
+    L.check(L.load().imd_conv_gemm(C.byref(p), cfg, _stream()))
+    return out
+
+
+def linear(x2d: torch.Tensor, w: torch.Tensor, bias=None, *, res=None, act=ACT_NONE, out_f32=False, out=None,
+           out_ld=None, res_ld=None, cfg=-1) -> torch.Tensor:
+    M, K = x2d.shape
+    N = w.shape[0]
+    return conv_gemm(x2d, w, M=M, N=N, Cin=K, bias=bias, res=res, act=act, out_f32=out_f32, out=out,
+                     out_ld=out_ld, res_ld=res_ld, cfg=cfg)
+
+
+def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
+                rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1) -> torch.Tensor:
+    """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout]."""
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
+    Ho, Wo = ((Hl + stride - 1) // stride, (Wl + stride - 1) // stride)
+    M = B * Ho * Wo
+    out = conv_gemm(x, w, M=M, N=Cout, Cin=Cin, taps=taps, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups,
+                    bias=bias, rowvec=rowvec, rowvec_stride=rowvec_stride, rowvec_off=rowvec_off, res=res, out_scale=out_scale, act=act,
+                    out_f32=out_f32, cfg=cfg)
+    return out.view(B, Ho, Wo, Cout)
+
+
+def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=None, scale2=None,
+              L2=0, L2P=0, kv2_bdiv=1, out_ld=None):
+    ensure_device(q.device)
+    p = L.AttnParams()
+    p.q, p.k1, p.v1t = _dev(q, bf16, "q"), _dev(k1, bf16, "k1"), _dev(v1t, bf16, "v1t")
+    p.k2, p.v2t = _opt(k2, bf16, "k2"), _opt(v2t, bf16, "v2t")
+    p.scale2 = _opt(scale2, torch.float32, "scale2")
+    p.out = _dev(out, bf16, "out")
+    p.B, p.H, p.N, p.D = B, H, N, D
+    p.L1, p.L1P, p.kv1_bdiv = L1, L1P, kv1_bdiv
+    p.L2, p.L2P, p.kv2_bdiv = L2, L2P, kv2_bdiv
+    p.out_ld = H * D if out_ld is None else out_ld
+    L.check(L.load().imd_attention(C.byref(p), _stream()))
+    return out
+
+
+def group_norm(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5, silu=False, out=None) -> torch.Tensor:
+    """x [B, HW, C] (or [B, H, W, C]) bf16 NHWC."""
+    ensure_device(x.device)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    if out is None:
+        out = torch.empty_like(x)
+    lib = L.load()
+    nws = lib.imd_groupnorm_workspace_floats(B, HW, Cc, groups)
+    part = workspace("gn_partial", (max(nws, 1),), torch.float32, x.device)
+    p = L.GroupNormParams()
+    p.x, p.y = _dev(x, bf16, "x"), _dev(out, bf16, "out")
+    p.gamma, p.beta = _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta")
+    p.partial = part.data_ptr()
+    p.B, p.HW, p.C, p.G, p.x_ld, p.y_ld = B, HW, Cc, groups, Cc, Cc
+    p.eps, p.silu = eps, int(silu)
+    L.check(lib.imd_groupnorm(C.byref(p), _stream()))
+    return out
+
+
+def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, out=None) -> torch.Tensor:
+    ensure_device(x.device)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if out is None:
+        out = torch.empty_like(x)
+    p = L.LayerNormParams()
+    p.x, p.y = _dev(x, bf16, "x"), _dev(out, bf16, "out")
+    p.gamma, p.beta = _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta")
+    p.rows, p.C, p.x_ld, p.y_ld, p.eps = rows, Cc, Cc, Cc, eps
+    L.check(L.load().imd_layernorm(C.byref(p), _stream()))
+    return out
+
+
+def ddim_cfg_step(z, eps, x_next, *, guidance, a_t, a_prev, mask=None, z_img=None, noise=None, a_next=None):
+    """z [B,HW,4] fp32 (in place); eps [2B,HW,4] fp32; x_next [2B,HW,8] bf16 or None."""
+    ensure_device(z.device)
+    B, HW = z.shape[0], z.shape[1]
+    p = L.DdimParams()
+    p.z, p.eps = _dev(z, torch.float32, "z"), _dev(eps, torch.float32, "eps")
+    p.x_next = _opt(x_next, bf16, "x_next")
+    p.B, p.HW = B, HW
+    p.guidance = guidance
+    p.sqrt_a_t, p.sqrt_1m_a_t = a_t ** 0.5, (1 - a_t) ** 0.5
+    p.sqrt_a_prev, p.sqrt_1m_a_prev = a_prev ** 0.5, (1 - a_prev) ** 0.5
+    p.mask = _opt(mask, torch.float32, "mask")
+    p.z_img = _opt(z_img, torch.float32, "z_img")
+    p.noise = _opt(noise, torch.float32, "noise")
+    if a_next is None:
+        p.sqrt_a_next, p.sqrt_1m_a_next = 1.0, 0.0
+    else:
+        p.sqrt_a_next, p.sqrt_1m_a_next = a_next ** 0.5, (1 - a_next) ** 0.5
+    L.check(L.load().imd_ddim_cfg_step(C.byref(p), _stream()))
+    return z
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    ensure_device(t.device)
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    L.check(L.load().imd_timestep_embedding(_dev(t, torch.float32, "t"), out.data_ptr(), t.shape[0], dim, _stream()))
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, b_scale: float = 1.0, out=None) -> torch.Tensor:
+    ensure_device(a.device)
+    Cc = a.shape[-1]
+    rows = a.numel() // Cc
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().imd_add(_dev(a, bf16, "a"), Cc, _dev(b, bf16, "b"), Cc, _dev(out, bf16, "out"), Cc, rows, Cc,
+                             b_scale, _stream()))
+    return out
+
+
+def concat_channels(a: torch.Tensor, b: torch.Tensor, b_add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """cat([a, b (+ b_add)], channel) for NHWC tensors [..., Ca] and [..., Cb]."""
+    ensure_device(a.device)
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    rows = a.numel() // Ca
+    out = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=bf16, device=a.device)
+    lib = L.load()
+    L.check(lib.imd_copy2d(_dev(a, bf16, "a"), Ca, out.data_ptr(), Ca + Cb, rows, Ca, _stream()))
+    if b_add is None:
+        L.check(lib.imd_copy2d(_dev(b, bf16, "b"), Cb, out.data_ptr() + 2 * Ca, Ca + Cb, rows, Cb, _stream()))
+    else:
+        L.check(lib.imd_add(_dev(b, bf16, "b"), Cb, _dev(b_add, bf16, "b_add"), Cb, out.data_ptr() + 2 * Ca, Ca + Cb,
+                            rows, Cb, 1.0, _stream()))
+    return out
+
+
+def f32_to_bf16(a: torch.Tensor) -> torch.Tensor:
+    ensure_device(a.device)
+    out = torch.empty(a.shape, dtype=bf16, device=a.device)
+    L.check(L.load().imd_f32_to_bf16(_dev(a, torch.float32, "a"), out.data_ptr(), a.numel(), _stream()))
+    return out

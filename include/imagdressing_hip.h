@@ -1,0 +1,149 @@
+/* imagdressing_hip.h -- C ABI of libimagdressing_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary of the IMAGDressing-v1 denoising hot path.  The reference is pure Python
+ * on this path (its device code is whatever torch dispatches to), so the "FFI" a maintainer binds
+ * is ctypes: see INTEGRATION.md for the stub.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers into HBM unless stated otherwise; bf16 tensors are passed
+ *     as uint16_t*.  Inputs are borrowed and must stay alive until the stream work completes.
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); kernels are only
+ *     enqueued, never synchronised; no allocation happens inside any call (hipGraph-capturable).
+ *   - Return value: 0 on success, non-zero on error; imd_last_error() returns the message
+ *     (thread-local).  There is NO CPU fallback: argument/shape/arch errors are reported, never
+ *     papered over.
+ *   - Activations are NHWC / token-major ([B, H*W, C]) bf16; weights are [N][K] bf16 with
+ *     k = (ky*3 + kx) * Cin + ci for 3x3 convolutions.
+ */
+#ifndef IMAGDRESSING_HIP_H
+#define IMAGDRESSING_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMD_ABI_VERSION 1
+
+enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2 };
+enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
+
+/* destination of one split (Q, K or V) of a head-split projection */
+typedef struct imd_heads_dest {
+    uint16_t* ptr; /* NULL: drop this split */
+    int kind;      /* 0: [B, H, L, DP] (rows = tokens)   1: [B, H, DP, L] (rows = head dim, keys contiguous) */
+    int DP;        /* kind 0: padded head dim (row length)   kind 1: rows per head */
+    int L;         /* kind 0: tokens per batch entry         kind 1: padded token count (row length) */
+    float scale;   /* multiplied in fp32 before rounding (softmax scale * log2 e folded into Q) */
+} imd_heads_dest;
+
+typedef struct imd_conv_gemm_params {
+    const uint16_t* x; /* NHWC activations (pixel stride x_pix_stride) or [M, K] rows */
+    const uint16_t* w; /* [N][K] */
+    void* out;         /* bf16 (fp32 when out_f32) [M, out_ld] */
+    int M, N, K;
+    int Cin, taps, Hin, Win, Hout, Wout, stride, ups;
+    int x_pix_stride;
+    int out_ld, res_ld;
+    const float* bias;   /* [N] or NULL */
+    const float* rowvec; /* per-batch vector [B][rowvec_stride] added to every pixel of batch b, or NULL */
+    int rowvec_stride;
+    const uint16_t* res; /* residual [M, res_ld] or NULL */
+    float out_scale;     /* applied after bias/rowvec, before the residual add */
+    int act;             /* IMD_ACT_* */
+    int out_f32;
+    int mode;            /* IMD_OUT_* */
+    int hC, hH, hD;      /* head split: channels per split, heads, head dim */
+    imd_heads_dest hd[3];
+} imd_conv_gemm_params;
+
+typedef struct imd_attn_params {
+    const uint16_t* q;   /* [B, H, N, DPK], pre-scaled by D^-1/2 * log2(e) */
+    const uint16_t* k1;  /* [B1, H, L1, DPK] */
+    const uint16_t* v1t; /* [B1, H, DPV, L1P] */
+    const uint16_t* k2;  /* optional second key/value set (garment tokens / IP tokens) or NULL */
+    const uint16_t* v2t;
+    const float* scale2; /* [B] weight of the second softmax branch per batch entry (0 => skipped) */
+    uint16_t* out;       /* [B, N, out_ld] with head h at columns h*D .. */
+    int B, H, N, D;
+    int L1, L1P, kv1_bdiv; /* kv batch entry of batch b is b / kv1_bdiv */
+    int L2, L2P, kv2_bdiv;
+    int out_ld;
+} imd_attn_params;
+
+typedef struct imd_groupnorm_params {
+    const uint16_t* x; uint16_t* y; const float* gamma; const float* beta;
+    float* partial;      /* workspace of imd_groupnorm_workspace_floats() floats */
+    int B, HW, C, G, x_ld, y_ld;
+    float eps;
+    int silu;
+} imd_groupnorm_params;
+
+typedef struct imd_layernorm_params {
+    const uint16_t* x; uint16_t* y; const float* gamma; const float* beta;
+    int rows, C, x_ld, y_ld;
+    float eps;
+} imd_layernorm_params;
+
+typedef struct imd_ddim_params {
+    float* z;             /* [B, HW, 4] fp32 latent state, updated in place */
+    const float* eps;     /* [2B, HW, 4] fp32: rows [0,B) cond pass, [B,2B) uncond pass */
+    uint16_t* x_next;     /* [2B, HW, 8] bf16 next UNet input (channels 4..7 = 0) or NULL */
+    int B, HW;
+    float guidance, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev;
+    const float* mask;    /* [B, HW] inpaint mask or NULL */
+    const float* z_img;   /* [B, HW, 4] */
+    const float* noise;   /* [B, HW, 4] */
+    float sqrt_a_next, sqrt_1m_a_next;
+} imd_ddim_params;
+
+/* library / device */
+int imd_abi_version(void);
+const char* imd_last_error(void);
+/* 0 iff `device` is a gfx950 part this library was built for. */
+int imd_device_check(int device);
+
+/* Implicit-GEMM convolution / linear layer with fused epilogue.
+ * Replaces (diffusers==0.24.0, called from dressing_sd/pipelines/IMAGDressing_v1_pipeline.py:466,499,511):
+ * ResnetBlock2D.conv1/conv2/conv_shortcut/time_emb_proj, Down/Upsample2D.conv, Transformer2DModel.proj_in/out,
+ * Attention.to_q/to_k/to_v/to_out[0], FeedForward (GEGLU), TimestepEmbedding, ControlNet zero-convs; and
+ * RefSAttnProcessor2_0.to_k_ref/to_v_ref (adapter/attention_processor.py:600-601), to_k_ip/to_v_ip (:841-842),
+ * the nn.Linear layers of adapter/resampler.py.  cfg: -1 auto, 0: 128x128x64, 1: 256x64x32, 2: 64x64x64 tiles. */
+int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
+int imd_conv_gemm_auto_cfg(int M, int N);
+
+/* Fused dual-softmax attention.  Replaces the two F.scaled_dot_product_attention calls + add of
+ * RefSAttnProcessor2_0.__call__ (adapter/attention_processor.py:589-612), LoRAIPAttnProcessor2_0 (:833-856),
+ * the single SDPA of CAttnProcessor2_0 (:277-279) / CacheAttnProcessor2_0 (:80-82), and
+ * PerceiverAttention's softmax(QK^T)V (adapter/resampler.py:71-74). */
+int imd_attention(const imd_attn_params* p, void* stream);
+/* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
+int imd_attn_padded_dims(int D, int* dpk, int* dpv);
+
+/* GroupNorm (+SiLU) over NHWC: diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out. */
+int imd_groupnorm(const imd_groupnorm_params* p, void* stream);
+int imd_groupnorm_workspace_floats(int B, int HW, int C, int G);
+
+/* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3; adapter/resampler.py:16,43-44,199. */
+int imd_layernorm(const imd_layernorm_params* p, void* stream);
+
+/* CFG combine + DDIM step (+ inpaint blend) + next UNet input:
+ * IMAGDressing_v1_pipeline.py:483-488,521-532; ..._pipeline_controlnet_inpainting.py:487-500. */
+int imd_ddim_cfg_step(const imd_ddim_params* p, void* stream);
+
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0): out[B, dim] fp32 = [cos | sin]. */
+int imd_timestep_embedding(const float* t, float* out, int B, int dim, void* stream);
+
+/* out = a + b_scale * b over [rows, C] with row strides (ControlNet residual add,
+ * ..._pipeline_ipa_controlnet.py:676-677,687-688; skip + residual). */
+int imd_add(const uint16_t* a, int a_ld, const uint16_t* b, int b_ld, uint16_t* out, int out_ld, long rows, int C, float b_scale, void* stream);
+/* strided 2-D copy (channel concat of UNet skip connections). */
+int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows, int C, void* stream);
+int imd_f32_to_bf16(const float* a, uint16_t* out, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGDRESSING_HIP_H */

@@ -1,0 +1,286 @@
+"""Per-kernel parity of the HIP path (through the C ABI) against plain fp32 torch references of the
+same op, on seeded inputs.  Tolerance: the north-star bar, atol 1e-2 on O(1) outputs computed in
+bf16 with fp32 accumulation (plus a relative term for large-magnitude GEMM outputs)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from imagdressing_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def assert_close(got, ref, atol=1e-2, rtol=1e-2, what=""):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    if bad.any():
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError(
+            f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max abs err {err.max().item():.4g} "
+            f"(ref max {ref.abs().max().item():.4g}); first bad index {idx}: got {got[tuple(idx)].item():.5g} "
+            f"ref {ref[tuple(idx)].item():.5g}")
+
+
+# ------------------------------------------------------------------------------------------
+# linear / GEMM
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [0, 1, 2, -1])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 320), (77, 64, 768), (8, 1280, 320), (130, 4, 72)])
+def test_linear(ops, cfg, M, N, K):
+    x = rnd(1, M, K).to(bf16)
+    w = rnd(2, N, K, scale=K ** -0.5).to(bf16)      # asymmetric: catches transposes
+    b = rnd(3, N)
+    ref = x.float() @ w.float().t() + b
+    out = ops.linear(dev(x), dev(w), dev(b), cfg=cfg)
+    assert out.dtype == bf16
+    assert_close(out, ref, what=f"linear cfg={cfg}")
+
+
+def test_linear_epilogues(ops):
+    M, N, K = 200, 128, 64
+    x = rnd(1, M, K).to(bf16); w = rnd(2, N, K, scale=K ** -0.5).to(bf16); b = rnd(3, N)
+    res = rnd(4, M, N).to(bf16)
+    base = x.float() @ w.float().t() + b
+    assert_close(ops.linear(dev(x), dev(w), dev(b), res=dev(res)), base + res.float(), what="residual")
+    assert_close(ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_SILU), F.silu(base), what="silu")
+    out32 = ops.linear(dev(x), dev(w), dev(b), out_f32=True)
+    assert out32.dtype == torch.float32
+    assert_close(out32, base, atol=2e-3, rtol=2e-3, what="fp32 out")
+    # GEGLU with interleaved (value, gate) rows
+    g = ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_GEGLU)
+    assert g.shape == (M, N // 2)
+    assert_close(g, base[:, 0::2] * F.gelu(base[:, 1::2]), what="geglu")
+
+
+def test_linear_no_bias_large_k(ops):
+    M, N, K = 512, 1280, 11520
+    x = rnd(5, M, K).to(bf16); w = rnd(6, N, K, scale=K ** -0.5).to(bf16)
+    ref = x.float() @ w.float().t()
+    assert_close(ops.linear(dev(x), dev(w)), ref, what="large K")
+
+
+# ------------------------------------------------------------------------------------------
+# convolution (implicit GEMM) vs F.conv2d
+# ------------------------------------------------------------------------------------------
+def pack_conv(w):  # [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
+    (2, 16, 16, 64, 64, 1, False), (1, 12, 20, 32, 320, 1, False), (2, 16, 16, 64, 128, 2, False),
+    (1, 8, 8, 64, 64, 1, True), (1, 9, 7, 8, 320, 1, False), (3, 6, 6, 320, 4, 1, False)])
+def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups):
+    x = rnd(1, B, Cin, H, W).to(bf16)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(bf16)
+    b = rnd(3, Cout)
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), taps=9, stride=stride,
+                          ups=ups, cfg=cfg)
+    assert_close(out, ref, what=f"conv3x3 cfg={cfg}")
+
+
+def test_conv_epilogue_rowvec_residual_scale(ops):
+    B, H, W, Cin, Cout = 2, 8, 8, 64, 128
+    x = rnd(1, B, Cin, H, W).to(bf16); w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(bf16)
+    b = rnd(3, Cout); temb = rnd(4, B, 256); res = rnd(5, B, H, W, Cout).to(bf16)
+    conv = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1)
+    ref = (conv + temb[:, None, None, 64:64 + Cout]) * 0.5 + res.float()
+    out = ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b),
+                          rowvec=dev(temb[:, 64:].contiguous()), rowvec_stride=192, res=dev(res), out_scale=0.5)
+    assert_close(out, ref, what="conv rowvec+res+scale")
+
+
+def test_conv1x1(ops):
+    B, H, W, Cin, Cout = 2, 8, 8, 320, 320
+    x = rnd(1, B, H, W, Cin).to(bf16); w = rnd(2, Cout, Cin, scale=Cin ** -0.5).to(bf16); b = rnd(3, Cout)
+    ref = x.float() @ w.float().t() + b
+    out = ops.conv2d_nhwc(dev(x), dev(w), dev(b), taps=1)
+    assert_close(out, ref, what="conv1x1")
+
+
+# ------------------------------------------------------------------------------------------
+# head-split epilogue + attention
+# ------------------------------------------------------------------------------------------
+def to_heads(x, H, DP, scale=1.0):
+    B, Lt, Cc = x.shape
+    d = Cc // H
+    out = torch.zeros(B, H, Lt, DP, dtype=bf16)
+    out[..., :d] = (x.float() * scale).to(bf16).view(B, Lt, H, d).transpose(1, 2)
+    return out
+
+
+def to_heads_t(x, H, DPV, LP):
+    B, Lt, Cc = x.shape
+    d = Cc // H
+    out = torch.zeros(B, H, DPV, LP, dtype=bf16)
+    out[:, :, :d, :Lt] = x.view(B, Lt, H, d).permute(0, 2, 3, 1)
+    return out
+
+
+def test_qkv_head_split(ops):
+    B, Lt, Cc, H = 2, 100, 320, 8
+    d = Cc // H
+    dpk, dpv = ops.attn_padded_dims(d)
+    LP = ops.pad64(Lt)
+    x = rnd(1, B * Lt, Cc).to(bf16); w = rnd(2, 3 * Cc, Cc, scale=Cc ** -0.5).to(bf16)
+    q = torch.zeros(B, H, Lt, dpk, dtype=bf16, device="cuda"); k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, dpv, LP, dtype=bf16, device="cuda")
+    ops.conv_gemm(dev(x), dev(w), M=B * Lt, N=3 * Cc, Cin=Cc, Hout=Lt, Wout=1, Hin=Lt, Win=1,
+                  heads=dict(C=Cc, H=H, D=d, dests=[(q, 0, dpk, Lt, 0.25), (k, 0, dpk, Lt, 1.0), (vt, 1, dpv, LP, 1.0)]))
+    y = (x.float() @ w.float().t()).view(B, Lt, 3 * Cc)
+    assert_close(q, to_heads(y[..., :Cc] * 0.25, H, dpk), what="q heads")
+    assert_close(k, to_heads(y[..., Cc:2 * Cc], H, dpk), what="k heads")
+    assert_close(vt, to_heads_t(y[..., 2 * Cc:].to(bf16), H, dpv, LP), what="v^T heads")
+
+
+def ref_attn(q, k, v, H):
+    from oracle.processors import sdpa
+    return sdpa(q.float(), k.float(), v.float(), H)
+
+
+@pytest.mark.parametrize("D,B,N,L1,L2", [
+    (40, 2, 200, 200, 330), (40, 1, 1100, 1100, 0), (80, 2, 144, 144, 100), (160, 1, 64, 64, 80),
+    (64, 2, 16, 273, 0), (40, 2, 130, 77, 4), (160, 1, 70, 77, 0)])
+def test_attention(ops, D, B, N, L1, L2):
+    H = 8
+    Cc = H * D
+    dpk, dpv = ops.attn_padded_dims(D)
+    q = rnd(1, B, N, Cc).to(bf16)
+    k1 = rnd(2, B, L1, Cc).to(bf16); v1 = rnd(3, B, L1, Cc).to(bf16)
+    scale = D ** -0.5 * math.log2(math.e)
+    qh = dev(to_heads(q, H, dpk, scale))
+    out = torch.empty(B, N, Cc, dtype=bf16, device="cuda")
+    ref = ref_attn(q, k1, v1, H)
+    kw = {}
+    if L2:
+        k2 = rnd(4, 1, L2, Cc).to(bf16); v2 = rnd(5, 1, L2, Cc).to(bf16)
+        s2 = torch.tensor([0.9, 0.0][:B] if B == 2 else [0.9])
+        r2 = ref_attn(q, k2.expand(B, -1, -1), v2.expand(B, -1, -1), H)
+        # phase 1 is rounded to bf16 before the add (the reference adds two half tensors, :612)
+        ref = ref.to(bf16).float() + s2[:, None, None] * r2
+        kw = dict(k2=dev(to_heads(k2, H, dpk)), v2t=dev(to_heads_t(v2, H, dpv, ops.pad64(L2))), scale2=dev(s2),
+                  L2=L2, L2P=ops.pad64(L2), kv2_bdiv=B)
+    ops.attention(qh, dev(to_heads(k1, H, dpk)), dev(to_heads_t(v1, H, dpv, ops.pad64(L1))), out,
+                  B=B, H=H, N=N, D=D, L1=L1, L1P=ops.pad64(L1), **kw)
+    assert_close(out, ref, atol=1e-2, rtol=1e-2, what=f"attention D={D}")
+
+
+def test_attention_shared_kv_batch_div(ops):
+    """text K/V computed once per prompt and shared by groups of batch rows (kv batch = b // bdiv)."""
+    D, H, B, N, L1 = 40, 8, 4, 96, 77
+    Cc = H * D
+    dpk, dpv = ops.attn_padded_dims(D)
+    q = rnd(1, B, N, Cc).to(bf16); k = rnd(2, 2, L1, Cc).to(bf16); v = rnd(3, 2, L1, Cc).to(bf16)
+    out = torch.empty(B, N, Cc, dtype=bf16, device="cuda")
+    ops.attention(dev(to_heads(q, H, dpk, D ** -0.5 * math.log2(math.e))), dev(to_heads(k, H, dpk)),
+                  dev(to_heads_t(v, H, dpv, 128)), out, B=B, H=H, N=N, D=D, L1=L1, L1P=128, kv1_bdiv=2)
+    ref = ref_attn(q, k.repeat_interleave(2, 0), v.repeat_interleave(2, 0), H)
+    assert_close(out, ref, what="kv batch div")
+
+
+def test_attention_softmax_spike(ops):
+    """A key far above the rest late in the sequence forces the online-softmax rescale path."""
+    D, H, B, N, L1 = 40, 8, 1, 64, 256
+    Cc = H * D
+    dpk, dpv = ops.attn_padded_dims(D)
+    q = rnd(1, B, N, Cc).to(bf16); k = rnd(2, B, L1, Cc).to(bf16); v = rnd(3, B, L1, Cc).to(bf16)
+    k[:, 200] = q[:, 5] * 4.0          # row 5 (and friends) suddenly meet a huge logit in tile 3
+    out = torch.empty(B, N, Cc, dtype=bf16, device="cuda")
+    ops.attention(dev(to_heads(q, H, dpk, D ** -0.5 * math.log2(math.e))), dev(to_heads(k, H, dpk)),
+                  dev(to_heads_t(v, H, dpv, 256)), out, B=B, H=H, N=N, D=D, L1=L1, L1P=256)
+    assert_close(out, ref_attn(q, k, v, H), atol=2e-2, what="spike")
+
+
+# ------------------------------------------------------------------------------------------
+# norms / elementwise
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,HW,Cc", [(2, 256, 320), (1, 100, 640), (2, 64, 960), (1, 70, 1280), (1, 16, 1920), (1, 9, 2560)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(ops, B, HW, Cc, silu):
+    x = (rnd(1, B, HW, Cc) * 1.5 + 0.3).to(bf16)
+    g = 1.0 + rnd(2, Cc, scale=0.2); b = rnd(3, Cc, scale=0.2)
+    ref = F.group_norm(x.float().transpose(1, 2), 32, g, b, eps=1e-5).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    out = ops.group_norm(dev(x), dev(g), dev(b), eps=1e-5, silu=silu)
+    assert_close(out, ref, atol=2e-2, rtol=1e-2, what="groupnorm")
+
+
+@pytest.mark.parametrize("rows,Cc", [(300, 320), (77, 768), (10, 1280), (5, 640)])
+def test_layernorm(ops, rows, Cc):
+    x = (rnd(1, rows, Cc) * 2 + 0.5).to(bf16)
+    g = 1.0 + rnd(2, Cc, scale=0.2); b = rnd(3, Cc, scale=0.2)
+    ref = F.layer_norm(x.float(), (Cc,), g, b, 1e-5)
+    assert_close(ops.layer_norm(dev(x), dev(g), dev(b)), ref, atol=2e-2, what="layernorm")
+
+
+def test_timestep_embedding(ops):
+    from oracle.sd15 import timestep_embedding
+    t = torch.tensor([981.0, 1.0, 500.0])
+    assert_close(ops.timestep_embedding(dev(t), 320), timestep_embedding(t, 320), atol=2e-3, rtol=0, what="timestep emb")
+
+
+@pytest.mark.parametrize("inpaint", [False, True])
+def test_ddim_cfg_step(ops, inpaint):
+    from oracle.ddim import DDIMOracle
+    B, HW = 3, 500
+    sch = DDIMOracle(); sch.set_timesteps(50)
+    t = int(sch.timesteps[7]); t_next = int(sch.timesteps[8])
+    z = rnd(1, B, HW, 4); eps = rnd(2, 2 * B, HW, 4); g = 7.5
+    e = eps[B:] + g * (eps[:B] - eps[B:])
+    ref = sch.step(e, t, z)
+    kw = {}
+    if inpaint:
+        mask = (rnd(3, B, HW) > 0).float(); zi = rnd(4, B, HW, 4); nz = rnd(5, B, HW, 4)
+        ref = (1 - mask[..., None]) * sch.add_noise(zi, nz, t_next) + mask[..., None] * ref
+        kw = dict(mask=dev(mask), z_img=dev(zi), noise=dev(nz), a_next=float(sch.alphas_cumprod[t_next]))
+    zd = dev(z.clone()); xn = torch.empty(2 * B, HW, 8, dtype=bf16, device="cuda")
+    prev_t = t - 1000 // 50
+    ops.ddim_cfg_step(zd, dev(eps), xn, guidance=g, a_t=float(sch.alphas_cumprod[t]),
+                      a_prev=float(sch.alphas_cumprod[prev_t]), **kw)
+    assert_close(zd, ref, atol=1e-4, rtol=1e-4, what="ddim z")
+    assert_close(xn[:B, :, :4], ref, atol=2e-2, what="next input cond")
+    assert_close(xn[B:, :, :4], ref, atol=2e-2, what="next input uncond")
+    assert float(xn[..., 4:].abs().max()) == 0.0
+
+
+def test_add_concat_cast(ops):
+    a = rnd(1, 2, 50, 320).to(bf16); b = rnd(2, 2, 50, 640).to(bf16); c = rnd(3, 2, 50, 640).to(bf16)
+    assert_close(ops.add(dev(b), dev(c), 0.5), b.float() + 0.5 * c.float(), what="add")
+    assert_close(ops.concat_channels(dev(a), dev(b)), torch.cat([a, b], -1), atol=0, rtol=0, what="concat")
+    assert_close(ops.concat_channels(dev(a), dev(b), dev(c)), torch.cat([a.float(), b.float() + c.float()], -1), what="concat+add")
+    f = rnd(4, 1000)
+    assert_close(ops.f32_to_bf16(dev(f)), f.to(bf16), atol=0, rtol=0, what="cast")
+
+
+def test_no_cpu_fallback(ops):
+    from imagdressing_amd._lib import ImdError
+    with pytest.raises(ImdError):
+        ops.linear(torch.zeros(8, 8, dtype=bf16), torch.zeros(8, 8, dtype=bf16))
