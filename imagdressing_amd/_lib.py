@@ -29,7 +29,7 @@ class ConvGemmParams(C.Structure):
         ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_stride", C.c_int),
         ("res", C.c_void_p), ("out_scale", C.c_float), ("act", C.c_int), ("out_f32", C.c_int),
         ("mode", C.c_int), ("hC", C.c_int), ("hH", C.c_int), ("hD", C.c_int),
-        ("hd", HeadsDest * 3),
+        ("hd", HeadsDest * 3), ("dtype", C.c_int),
     ]
 
 
@@ -40,7 +40,7 @@ class AttnParams(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("D", C.c_int),
         ("L1", C.c_int), ("L1P", C.c_int), ("kv1_bdiv", C.c_int),
         ("L2", C.c_int), ("L2P", C.c_int), ("kv2_bdiv", C.c_int),
-        ("out_ld", C.c_int),
+        ("out_ld", C.c_int), ("dtype", C.c_int),
     ]
 
 
@@ -48,14 +48,14 @@ class GroupNormParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partial", C.c_void_p),
         ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("G", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int),
-        ("eps", C.c_float), ("silu", C.c_int),
+        ("eps", C.c_float), ("silu", C.c_int), ("dtype", C.c_int),
     ]
 
 
 class LayerNormParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
-        ("rows", C.c_int), ("C", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int), ("eps", C.c_float),
+        ("rows", C.c_int), ("C", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int), ("eps", C.c_float), ("dtype", C.c_int),
     ]
 
 
@@ -66,7 +66,7 @@ class DdimParams(C.Structure):
         ("guidance", C.c_float), ("sqrt_a_t", C.c_float), ("sqrt_1m_a_t", C.c_float),
         ("sqrt_a_prev", C.c_float), ("sqrt_1m_a_prev", C.c_float),
         ("mask", C.c_void_p), ("z_img", C.c_void_p), ("noise", C.c_void_p),
-        ("sqrt_a_next", C.c_float), ("sqrt_1m_a_next", C.c_float),
+        ("sqrt_a_next", C.c_float), ("sqrt_1m_a_next", C.c_float), ("dtype", C.c_int),
     ]
 
 
@@ -84,9 +84,9 @@ SYMBOLS = {
     "imd_layernorm": (C.c_int, [C.POINTER(LayerNormParams), C.c_void_p]),
     "imd_ddim_cfg_step": (C.c_int, [C.POINTER(DdimParams), C.c_void_p]),
     "imd_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
-    "imd_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float, C.c_void_p]),
+    "imd_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "imd_copy2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
-    "imd_f32_to_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    "imd_f32_to_16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,466 @@
+"""Attention processors of IMAGDressing-v1 on the fused HIP path (the plugin surface).
+
+Same class names, constructor signatures, ``state_dict`` keys and mutable attributes
+(``.scale``, ``.lora_scale``, ``.name``, ``.cache["hidden_states"]``) as
+``/root/reference/adapter/attention_processor.py`` so that
+``unet.set_attn_processor({...})``, ``ModuleList(unet.attn_processors.values()).load_state_dict``
+(inference_IMAGdressing.py:85-87,117) and ``pipe.set_scale`` keep working, and the same call
+protocol ``proc(attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+scale=1.0, **cross_attention_kwargs)``.
+
+What differs is *how* a call executes.  Per attention layer the reference launches 6 GEMMs, 6
+reshapes, 2 SDPAs and an add (attention_processor.py:568-617); here it is three launches:
+
+  1. one GEMM whose epilogue writes Q (pre-scaled by d^-1/2 log2 e), K and V^T straight into the
+     per-head layouts the attention kernel wants,
+  2. one fused attention kernel running BOTH softmaxes (self + garment, or text + IP tokens) and
+     summing them before anything leaves registers,
+  3. the out-projection GEMM with bias and the transformer block's residual add in its epilogue.
+
+Step-invariant operands are projected once and cached on the processor: the garment K_ref/V_ref
+(the reference re-projects them at every step, :600-601), the text / IP-token K/V, and LoRA deltas,
+which are folded into effective weights W + lambda * up @ down whenever ``lora_scale`` changes.
+
+Extensions over the reference (all optional, all default to reference behaviour):
+  * ``sa_batch_mask`` (cross_attention_kwargs): float tensor [B]; the garment branch is applied to
+    batch row b with weight ``scale * sa_batch_mask[b]``.  Lets cond and uncond rows of a CFG batch
+    share one UNet call (the reference issues two B=1 calls, IMAGDressing_v1_pipeline.py:499-518).
+  * garment tokens [1, M, C] broadcast over the batch (the reference's ``view(batch_size, ...)`` at
+    :602-603 is only defined for B == 1).
+  * ``encoder_hidden_states`` with fewer rows than ``hidden_states`` is shared by contiguous groups
+    of batch rows.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+bf16 = torch.bfloat16
+LOG2E = math.log2(math.e)
+
+
+class LoRALinearLayer(nn.Module):
+    """Parameter container with the diffusers-0.24 ``LoRALinearLayer`` layout (down / up)."""
+
+    def __init__(self, in_features, out_features, rank=4, network_alpha=None):
+        super().__init__()
+        self.down = nn.Linear(in_features, rank, bias=False)
+        self.up = nn.Linear(rank, out_features, bias=False)
+        self.network_alpha = network_alpha
+        self.rank = rank
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+
+    def delta(self) -> torch.Tensor:
+        """up @ down (* alpha / rank) in fp32 -- the matrix added to the frozen weight."""
+        d = self.up.weight.float() @ self.down.weight.float()
+        if self.network_alpha is not None:
+            d = d * (self.network_alpha / self.rank)
+        return d
+
+
+def _version_key(*tensors) -> Tuple:
+    return tuple((t.data_ptr(), t._version, t.device, t.dtype) for t in tensors)
+
+
+class _TensorCache:
+    """Small LRU of values cached against the *identity and version* of their source tensors (which the
+    cache keeps alive, so an address can never be recycled under it).  A few entries, because the
+    reference-style loop alternates two conditionings per step (cond / uncond UNet calls)."""
+
+    def __init__(self, capacity: int = 4):
+        self._entries = []          # [(srcs, key, value)], most recent last
+        self._cap = capacity
+
+    def get(self, srcs, extra=()):
+        key = (_version_key(*srcs), extra)
+        for i, (s, k, v) in enumerate(self._entries):
+            if k == key and len(s) == len(srcs) and all(a is b for a, b in zip(s, srcs)):
+                if i != len(self._entries) - 1:
+                    self._entries.append(self._entries.pop(i))
+                return v
+        return None
+
+    def put(self, srcs, value, extra=()):
+        self._entries.append((tuple(srcs), (_version_key(*srcs), extra), value))
+        if len(self._entries) > self._cap:
+            self._entries.pop(0)
+        return value
+
+
+def _as_tokens(hidden_states: torch.Tensor, dtype):
+    """Accept [B, N, C] (transformer blocks) or [B, C, H, W] (attention_processor.py:548-552); cast to the
+    16-bit element type of the layer's packed weights (bf16 or fp16)."""
+    shape4 = None
+    if hidden_states.dim() == 4:
+        b, c, h, w = hidden_states.shape
+        shape4 = (b, c, h, w)
+        hidden_states = hidden_states.view(b, c, h * w).transpose(1, 2)
+    if not hidden_states.is_cuda:
+        from .._lib import ImdError
+        raise ImdError("imagdressing_amd processors run on MI355X only: hidden_states is on " + str(hidden_states.device))
+    return hidden_states.to(dtype).contiguous(), shape4
+
+
+def _restore(out, shape4, like):
+    if shape4 is not None:
+        b, c, h, w = shape4
+        out = out.transpose(-1, -2).reshape(b, c, h, w)
+    return out
+
+
+def _project_kv(tokens: torch.Tensor, wkv: torch.Tensor, heads: int):
+    """tokens [Bk, L, Kd] bf16, wkv [2C, Kd] -> (K [Bk,H,L,dpk], V^T [Bk,H,dpv,LP], L, LP) in freshly
+    zeroed persistent buffers (their padding must stay zero)."""
+    Bk, Lk, Kd = tokens.shape
+    Cc = wkv.shape[0] // 2
+    D = Cc // heads
+    dpk, dpv = ops.attn_padded_dims(D)
+    LP = ops.pad64(Lk)
+    k = torch.zeros(Bk, heads, Lk, dpk, dtype=wkv.dtype, device=tokens.device)
+    vt = torch.zeros(Bk, heads, dpv, LP, dtype=wkv.dtype, device=tokens.device)
+    ops.conv_gemm(tokens.view(Bk * Lk, Kd), wkv, M=Bk * Lk, N=2 * Cc, Cin=Kd, Hin=Lk, Win=1, Hout=Lk, Wout=1,
+                  heads=dict(C=Cc, H=heads, D=D, dests=[(k, 0, dpk, Lk, 1.0), (vt, 1, dpv, LP, 1.0)]))
+    return k, vt, Lk, LP
+
+
+def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, self_attn: bool,
+                     kv1=None, kv1_bdiv: int = 1, kv2=None, kv2_bdiv: int = 1, scale2: Optional[torch.Tensor] = None,
+                     wo: torch.Tensor, bo: Optional[torch.Tensor], residual: Optional[torch.Tensor]) -> torch.Tensor:
+    """x [B, N, C] bf16 -> out-projected attention output [B, N, C] (+ residual)."""
+    B, N, Cc = x.shape
+    D = Cc // heads
+    dpk, dpv = ops.attn_padded_dims(D)
+    dev, dt = x.device, x.dtype
+    q = ops.workspace("attn_q", (B, heads, N, dpk), dt, dev)
+    qscale = D ** -0.5 * LOG2E
+    x2 = x.view(B * N, Cc)
+    if self_attn:
+        LP = ops.pad64(N)
+        k = ops.workspace("attn_k", (B, heads, N, dpk), dt, dev)
+        vt = ops.workspace("attn_vt", (B, heads, dpv, LP), dt, dev)
+        ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=3 * Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1,
+                      heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale), (k, 0, dpk, N, 1.0), (vt, 1, dpv, LP, 1.0)]))
+        kv1, kv1_bdiv = (k, vt, N, LP), 1
+    else:
+        ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1,
+                      heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale)]))
+    o = torch.empty(B, N, Cc, dtype=dt, device=dev)
+    kw = {}
+    if kv2 is not None and scale2 is not None:
+        kw = dict(k2=kv2[0], v2t=kv2[1], L2=kv2[2], L2P=kv2[3], kv2_bdiv=kv2_bdiv, scale2=scale2)
+    ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, **kw)
+    res2 = None if residual is None else residual.view(B * N, Cc)
+    return ops.linear(o.view(B * N, Cc), wo, bo, res=res2).view(B, N, Cc)
+
+
+class _FusedBase:
+    fused_residual = True     # the engine hands the block residual in and skips its own add
+
+    @staticmethod
+    def _ehs_bdiv(B: int, ehs: torch.Tensor) -> int:
+        Be = ehs.shape[0]
+        if B % Be:
+            raise ValueError(f"encoder_hidden_states batch {Be} does not divide hidden_states batch {B}")
+        return B // Be
+
+    @staticmethod
+    def _finish(attn, out, residual_given, like, shape4):
+        # attn.residual_connection / rescale_output_factor are False / 1.0 for SD1.5 (:622-625)
+        if getattr(attn, "residual_connection", False) and not residual_given:
+            out = ops.add(out, like)
+        if getattr(attn, "rescale_output_factor", 1.0) != 1.0:
+            raise NotImplementedError("rescale_output_factor != 1 is not used by SD1.5")
+        return _restore(out, shape4, like)
+
+
+class AttnProcessor2_0(_FusedBase):
+    """Plain attention (diffusers' default processor; what a ControlNet / un-patched UNet runs)."""
+
+    def __init__(self):
+        self._text = _TensorCache()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 imd_residual=None, **kwargs):
+        x, shape4 = _as_tokens(hidden_states, attn.to_q.weight.dtype)
+        wo, bo = attn.to_out[0].weight, attn.to_out[0].bias
+        if encoder_hidden_states is None:
+            out = _fused_attention(x, attn.heads, wq_or_qkv=attn.packed("qkv"), self_attn=True, wo=wo, bo=bo,
+                                   residual=imd_residual)
+        else:
+            kv = self._text.get((encoder_hidden_states,))
+            if kv is None:
+                e = encoder_hidden_states.to(device=x.device, dtype=x.dtype).contiguous()
+                kv = self._text.put((encoder_hidden_states,), _project_kv(e, attn.packed("kv"), attn.heads))
+            out = _fused_attention(x, attn.heads, wq_or_qkv=attn.to_q.weight, self_attn=False, kv1=kv,
+                                   kv1_bdiv=self._ehs_bdiv(x.shape[0], encoder_hidden_states), wo=wo, bo=bo,
+                                   residual=imd_residual)
+        return self._finish(attn, out, imd_residual is not None, x, shape4)
+
+
+class CacheAttnProcessor2_0(AttnProcessor2_0):
+    """Garment-UNet processor: remembers its *input* (attention_processor.py:34), then plain attention."""
+
+    def __init__(self):
+        super().__init__()
+        self.cache = {}
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 **kwargs):
+        self.cache["hidden_states"] = hidden_states
+        return super().__call__(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, **kwargs)
+
+
+class _RefMixin:
+    """Garment branch state shared by the three hybrid processors."""
+
+    def _init_ref(self, name, hidden_size, cross_attention_dim, scale):
+        self.name = name
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self.to_k_ref = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.to_v_ref = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.scale = scale
+        self._wref = _TensorCache()
+        self._garment = _TensorCache()
+        self._scale2 = _TensorCache()
+        self._scale2_plain: Dict = {}
+
+    def _garment_kv(self, ref: torch.Tensor, heads: int, device, dtype):
+        """K_ref / V_ref of the garment tokens, projected ONCE per garment (step-invariant)."""
+        wsrc = (self.to_k_ref.weight, self.to_v_ref.weight)
+        kv = self._garment.get((ref,) + wsrc, extra=(dtype,))
+        if kv is None:
+            w = self._wref.get(wsrc, extra=(dtype,))
+            if w is None:
+                w = self._wref.put(wsrc, torch.cat([t.detach().to(device=device, dtype=dtype) for t in wsrc], 0).contiguous(),
+                                   extra=(dtype,))
+            r = ref.detach().to(device=device, dtype=dtype).contiguous()
+            if r.dim() != 3:
+                raise ValueError(f"sa_hidden_states[{self.name!r}] must be [1, M, C], got {tuple(ref.shape)}")
+            kv = self._garment.put((ref,) + wsrc, _project_kv(r, w, heads), extra=(dtype,))
+        return kv
+
+    def _branch_weights(self, B: int, mask: Optional[torch.Tensor], device) -> torch.Tensor:
+        """[B] fp32 = scale (* sa_batch_mask)."""
+        s = float(self.scale)
+        if mask is None:
+            t = self._scale2_plain.get((B, s, str(device)))
+            if t is None:
+                t = torch.full((B,), s, dtype=torch.float32, device=device)
+                self._scale2_plain = {(B, s, str(device)): t}
+            return t
+        t = self._scale2.get((mask,), extra=(s,))
+        if t is None:
+            t = self._scale2.put((mask,), (mask.to(device=device, dtype=torch.float32) * s).contiguous(), extra=(s,))
+        return t
+
+
+class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
+    """Hybrid attention: frozen self-attention + trainable garment cross-attention
+    (attention_processor.py:513-627)."""
+
+    def __init__(self, name, hidden_size, cross_attention_dim=None, scale=1.0):
+        super().__init__()
+        self._init_ref(name, hidden_size, cross_attention_dim, scale)
+
+    def _weights(self, attn):
+        return attn.packed("qkv"), attn.to_out[0].weight, attn.to_out[0].bias
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 num_images_per_prompt=1, cond_hidden_states=None, sa_hidden_states=None, sa_batch_mask=None,
+                 imd_residual=None, **kwargs):
+        if encoder_hidden_states is not None:
+            raise NotImplementedError(f"{type(self).__name__} is a self-attention (attn1) processor")
+        x, shape4 = _as_tokens(hidden_states, attn.to_q.weight.dtype)
+        wqkv, wo, bo = self._weights(attn)
+        kv2 = s2 = None
+        if sa_hidden_states is not None:                                   # :597
+            kv2 = self._garment_kv(sa_hidden_states[self.name], attn.heads, x.device, x.dtype)
+            s2 = self._branch_weights(x.shape[0], sa_batch_mask, x.device)
+        out = _fused_attention(x, attn.heads, wq_or_qkv=wqkv, self_attn=True, kv2=kv2, kv2_bdiv=max(x.shape[0], 1),
+                               scale2=s2, wo=wo, bo=bo, residual=imd_residual)
+        return self._finish(attn, out, imd_residual is not None, x, shape4)
+
+
+class _LoraFold:
+    """W_eff = W + lora_scale * up @ down, recomputed only when lora_scale or the LoRA tensors change."""
+
+    def _init_lora(self, hidden_size, kdim, rank, network_alpha, lora_scale):
+        self.rank = rank
+        self.lora_scale = lora_scale
+        self.to_q_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
+        self.to_k_lora = LoRALinearLayer(kdim, hidden_size, rank, network_alpha)
+        self.to_v_lora = LoRALinearLayer(kdim, hidden_size, rank, network_alpha)
+        self.to_out_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
+        self._folded = _TensorCache()
+
+    def _fold(self, attn, device):
+        ls = float(self.lora_scale)
+        srcs = tuple(l.weight for lo in (self.to_q_lora, self.to_k_lora, self.to_v_lora, self.to_out_lora)
+                     for l in (lo.down, lo.up)) + (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight)
+        w = self._folded.get(srcs, extra=(ls,))
+        if w is None:
+            def eff(base, lora):
+                if ls == 0.0:
+                    return base
+                return (base.float() + ls * lora.delta().to(device)).to(base.dtype).contiguous()
+            wq, wk, wv = eff(attn.to_q.weight, self.to_q_lora), eff(attn.to_k.weight, self.to_k_lora), eff(attn.to_v.weight, self.to_v_lora)
+            wo = eff(attn.to_out[0].weight, self.to_out_lora)
+            w = self._folded.put(srcs, dict(q=wq, kv=torch.cat([wk, wv], 0).contiguous(),
+                                            qkv=(torch.cat([wq, wk, wv], 0).contiguous() if wk.shape[1] == wq.shape[1] else None),
+                                            o=wo), extra=(ls,))
+        return w
+
+
+class _LoraRefSBase(nn.Module, _FusedBase, _RefMixin, _LoraFold):
+    """Hybrid attention with rank-``rank`` LoRA on q/k/v/out.  Deliberately NOT a subclass of
+    RefSAttnProcessor2_0: the reference pipelines select processors with isinstance checks
+    (IMAGDressing_v1_pipeline.py:342-345, ..._ipa_controlnet.py:379-383) and the classes are siblings."""
+
+    def __init__(self, name, hidden_size, cross_attention_dim=None, scale=1.0, rank=128, network_alpha=None, lora_scale=1.0):
+        super().__init__()
+        self._init_ref(name, hidden_size, cross_attention_dim, scale)
+        self._init_lora(hidden_size, cross_attention_dim or hidden_size, rank, network_alpha, lora_scale)
+
+    def _weights(self, attn):
+        w = self._fold(attn, attn.to_q.weight.device)
+        return w["qkv"], w["o"], attn.to_out[0].bias
+
+    __call__ = RefSAttnProcessor2_0.__call__
+
+
+class LoraRefSAttnProcessor2_0(_LoraRefSBase):
+    """attention_processor.py:391-511 (used by inference_IMAGdressing_ipa_controlnetpose.py:88-94)."""
+
+
+class RefLoraSAttnProcessor2_0(_LoraRefSBase):
+    """Same arithmetic under the name ``app.py:90`` uses (attention_processor.py:1006-1128).  As in the
+    reference, ``pipe.set_scale`` does not match this class (it checks LoraRefSAttnProcessor2_0)."""
+
+
+class CAttnProcessor2_0(nn.Module, _FusedBase):
+    """Text cross-attention (attention_processor.py:202-295); ignores ``sa_hidden_states``."""
+
+    def __init__(self, name, hidden_size, cross_attention_dim=None):
+        super().__init__()
+        self.name = name
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self._plain = AttnProcessor2_0()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 cond_hidden_states=None, sa_hidden_states=None, imd_residual=None, **kwargs):
+        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
+
+
+class _IPBase(nn.Module, _FusedBase, _LoraFold):
+    """Text cross-attention + IP-Adapter tokens (+ LoRA): the last ``num_tokens`` rows of
+    ``encoder_hidden_states`` are the face tokens (split at attention_processor.py:811-815)."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, rank=4, network_alpha=None, lora_scale=1.0, scale=1.0,
+                 num_tokens=4):
+        super().__init__()
+        self.num_tokens = num_tokens
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self.scale = scale
+        self._init_lora(hidden_size, cross_attention_dim or hidden_size, rank, network_alpha, lora_scale)
+        self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self._kv = _TensorCache()
+        self._wip = _TensorCache()
+        self._s2: Dict = {}
+
+    def _weights(self, attn):
+        w = self._fold(attn, attn.to_q.weight.device)
+        return w["q"], w["kv"], w["o"]
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, temb=None,
+                 *args, imd_residual=None, **kwargs):
+        if encoder_hidden_states is None:
+            raise NotImplementedError(f"{type(self).__name__} is a cross-attention (attn2) processor")
+        x, shape4 = _as_tokens(hidden_states, attn.to_q.weight.dtype)
+        wq, wkv, wo = self._weights(attn)
+        wsrc = (self.to_k_ip.weight, self.to_v_ip.weight)
+        ls = float(getattr(self, "lora_scale", 0.0))
+        kvs = self._kv.get((encoder_hidden_states,) + wsrc, extra=(ls, x.dtype))
+        if kvs is None:
+            wip = self._wip.get(wsrc, extra=(x.dtype,))
+            if wip is None:
+                wip = self._wip.put(wsrc, torch.cat([t.detach().to(device=x.device, dtype=x.dtype) for t in wsrc], 0).contiguous(),
+                                    extra=(x.dtype,))
+            e = encoder_hidden_states.to(device=x.device, dtype=x.dtype)
+            end = e.shape[1] - self.num_tokens                                       # :811
+            kvs = self._kv.put((encoder_hidden_states,) + wsrc,
+                               (_project_kv(e[:, :end].contiguous(), wkv, attn.heads),
+                                _project_kv(e[:, end:].contiguous(), wip, attn.heads)), extra=(ls, x.dtype))
+        B = x.shape[0]
+        key = (B, float(self.scale), str(x.device))
+        s2 = self._s2.get(key)
+        if s2 is None:
+            s2 = torch.full((B,), float(self.scale), dtype=torch.float32, device=x.device)
+            self._s2 = {key: s2}
+        bdiv = self._ehs_bdiv(B, encoder_hidden_states)
+        out = _fused_attention(x, attn.heads, wq_or_qkv=wq, self_attn=False, kv1=kvs[0], kv1_bdiv=bdiv, kv2=kvs[1],
+                               kv2_bdiv=bdiv, scale2=s2, wo=wo, bo=attn.to_out[0].bias, residual=imd_residual)
+        return self._finish(attn, out, imd_residual is not None, x, shape4)
+
+
+class LoRAIPAttnProcessor2_0(_IPBase):
+    """attention_processor.py:746-871."""
+
+
+class IPAttnProcessor2_0(_IPBase):
+    """IP-Adapter cross-attention without LoRA (attention_processor.py:873-1003).  The reference also
+    computes an unused ``attn_map`` every call (:981-982); that dead work is not replicated."""
+
+    def __init__(self, hidden_size, cross_attention_dim=None, scale=1.0, num_tokens=4):
+        nn.Module.__init__(self)
+        self.num_tokens = num_tokens
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        self.scale = scale
+        self.to_k_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
+        self._kv = _TensorCache()
+        self._wip = _TensorCache()
+        self._s2 = {}
+
+    def _weights(self, attn):
+        return attn.to_q.weight, attn.packed("kv"), attn.to_out[0].weight
+
+
+# ---- legacy names: defined by the reference but used by none of its entry points ----------------
+class BaseSAttnProcessor2_0(nn.Module, _FusedBase):
+    """Plain self-attention with a name (attention_processor.py:298-389)."""
+
+    def __init__(self, name, hidden_size, cross_attention_dim=None):
+        super().__init__()
+        self.name, self.hidden_size, self.cross_attention_dim = name, hidden_size, cross_attention_dim
+        self._plain = AttnProcessor2_0()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 imd_residual=None, **kwargs):
+        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
+
+
+class SAttnProcessor2_0(BaseSAttnProcessor2_0):
+    """Concat-KV variant (attention_processor.py:103-199, ONE softmax over [self; garment] keys, :157-159).
+    Unused by every reference entry point; kept importable, executes plain self-attention when no
+    garment tokens are passed and refuses the concat form (different arithmetic from the hybrid)."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, sa_hidden_states=None, **kwargs):
+        if sa_hidden_states is not None:
+            raise NotImplementedError("SAttnProcessor2_0 (single softmax over concatenated keys) is legacy and unused; "
+                                      "use RefSAttnProcessor2_0")
+        return super().__call__(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, **kwargs)
+
+
+class RefCAttnProcessor2_0(CAttnProcessor2_0):
+    """Legacy name (attention_processor.py:630-743); unused by the reference's entry points."""

@@ -45,9 +45,10 @@ template <int D> struct AttnCfg {
     static constexpr int VVECS = (D * (KT / 8) + 255) / 256;
 };
 
-template <int D, int QW, int MINW>
+template <bool F16, int D, int QW, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     using C = AttnCfg<D>;
+    using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 #pragma unroll
                     for (int tk = 0; tk < C::NKT; ++tk) {
                         const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kb * 32 * C::KSTR + kfrag + tk * 32);
-                        s[kb] = mfma32(kf, qf[qb][tk], s[kb]);
+                        s[kb] = E::mfma(kf, qf[qb][tk], s[kb]);
                     }
                 }
                 if (ragged) {     // keys >= L of the last tile contribute nothing
@@ -211,10 +212,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int kb = g >> 1, r0 = (g & 1) * 8;
-                    pf[g].x = pack_bf2(s[kb][r0 + 0], s[kb][r0 + 1]);
-                    pf[g].y = pack_bf2(s[kb][r0 + 2], s[kb][r0 + 3]);
-                    pf[g].z = pack_bf2(s[kb][r0 + 4], s[kb][r0 + 5]);
-                    pf[g].w = pack_bf2(s[kb][r0 + 6], s[kb][r0 + 7]);
+                    pf[g].x = E::pack2(s[kb][r0 + 0], s[kb][r0 + 1]);
+                    pf[g].y = E::pack2(s[kb][r0 + 2], s[kb][r0 + 3]);
+                    pf[g].z = E::pack2(s[kb][r0 + 4], s[kb][r0 + 5]);
+                    pf[g].w = E::pack2(s[kb][r0 + 6], s[kb][r0 + 7]);
                 }
                 // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + g * 32);
-                        o[qb][dt] = mfma32(vf, pf[g], o[qb][dt]);
+                        o[qb][dt] = E::mfma(vf, pf[g], o[qb][dt]);
                     }
             }
             if (t + 1 < ntiles) store_tile((t + 1) & 1);
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 #pragma unroll
                 for (int dt = 0; dt < C::NDT; ++dt) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) o1[qb][dt][r] = pack_bf2(o[qb][dt][2 * r], o[qb][dt][2 * r + 1]);
+                    for (int r = 0; r < 8; ++r) o1[qb][dt][r] = E::pack2(o[qb][dt][2 * r], o[qb][dt][2 * r + 1]);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
                 }
@@ -270,20 +271,20 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * j + e;
                     const uint32_t w = o1[qb][dt][r >> 1];
-                    const float first = (r & 1) ? bf_hi(w) : bf_lo(w);
+                    const float first = (r & 1) ? E::hi(w) : E::lo(w);
                     v[e] = first + wgt * o[qb][dt][r];
                 }
-                *reinterpret_cast<uint2*>(orow + dd) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                *reinterpret_cast<uint2*>(orow + dd) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
             }
     }
 }
 
-template <int D, int QW, int MINW>
+template <bool F16, int D, int QW, int MINW>
 int launch_attn(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
     constexpr int lds = 2 * C::BUF;
     static bool attr_set = false;
-    auto kern = attn_kernel<D, QW, MINW>;
+    auto kern = attn_kernel<F16, D, QW, MINW>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -306,11 +307,13 @@ int imd_launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.k2 && (p.L2 <= 0 || p.L2P % 64 || p.L2P < p.L2)) return imd_set_error("attention: bad second key set L2=%d L2P=%d", p.L2, p.L2P);
     if (p.kv1_bdiv <= 0 || (p.k2 && p.kv2_bdiv <= 0)) return imd_set_error("attention: kv batch divisors must be positive");
     if (p.H > 65535 || p.B > 65535) return imd_set_error("attention: H/B exceed grid limits");
+    if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("attention: unknown dtype %d", p.dtype);
+    const bool h = p.dtype == IMD_DTYPE_F16;
     switch (p.D) {
-        case 40: return (p.N >= 1024) ? launch_attn<40, 2, 2>(p, s) : launch_attn<40, 1, 2>(p, s);
-        case 64: return launch_attn<64, 1, 2>(p, s);
-        case 80: return launch_attn<80, 1, 2>(p, s);
-        case 160: return launch_attn<160, 1, 1>(p, s);
+        case 40: return h ? launch_attn<true, 40, 1, 2>(p, s) : launch_attn<false, 40, 1, 2>(p, s);
+        case 64: return h ? launch_attn<true, 64, 1, 2>(p, s) : launch_attn<false, 64, 1, 2>(p, s);
+        case 80: return h ? launch_attn<true, 80, 1, 2>(p, s) : launch_attn<false, 80, 1, 2>(p, s);
+        case 160: return h ? launch_attn<true, 160, 1, 1>(p, s) : launch_attn<false, 160, 1, 1>(p, s);
         default: return imd_set_error("attention: unsupported head dim %d (supported: 40, 64, 80, 160)", p.D);
     }
 }

@@ -94,9 +94,9 @@ int imd_timestep_embedding(const float* t, float* out, int B, int dim, void* str
     return imd_launch_timestep_embedding(t, out, B, dim, (hipStream_t)stream);
 }
 
-int imd_add(const uint16_t* a, int a_ld, const uint16_t* b, int b_ld, uint16_t* out, int out_ld, long rows, int C, float b_scale, void* stream) {
+int imd_add(const uint16_t* a, int a_ld, const uint16_t* b, int b_ld, uint16_t* out, int out_ld, long rows, int C, float b_scale, int dtype, void* stream) {
     IMD_REQUIRE(a && b && out, "add: null pointer");
-    return imd_launch_add(a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale, (hipStream_t)stream);
+    return imd_launch_add(a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale, dtype, (hipStream_t)stream);
 }
 
 int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows, int C, void* stream) {
@@ -104,9 +104,9 @@ int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows
     return imd_launch_copy2d(a, a_ld, out, out_ld, rows, C, (hipStream_t)stream);
 }
 
-int imd_f32_to_bf16(const float* a, uint16_t* out, long n, void* stream) {
-    IMD_REQUIRE(a && out, "f32_to_bf16: null pointer");
-    return imd_launch_f32_to_bf16(a, out, n, (hipStream_t)stream);
+int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream) {
+    IMD_REQUIRE(a && out, "f32_to_16: null pointer");
+    return imd_launch_f32_to_16(a, out, n, dtype, (hipStream_t)stream);
 }
 
 }  // extern "C"

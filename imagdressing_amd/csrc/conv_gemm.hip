@@ -25,8 +25,9 @@
 
 namespace {
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+    using E = El<F16>;
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int STRIDE = BK * 2 + 16;        // bytes per LDS row (odd number of 16-B slots)
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
-                for (int b = 0; b < TM; ++b) acc[a][b] = mfma32(wf[a], xf[b], acc[a][b]);
+                for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
         }
         if (t + 1 < nk) store_tile((t + 1) & 1);
         __syncthreads();
@@ -185,11 +186,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
                 }
                 if (p.res) {
                     const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
-                    v[0] += bf_lo(rr.x); v[1] += bf_hi(rr.x); v[2] += bf_lo(rr.y); v[3] += bf_hi(rr.y);
+                    v[0] += E::lo(rr.x); v[1] += E::hi(rr.x); v[2] += E::lo(rr.y); v[3] += E::hi(rr.y);
                 }
                 if (p.act == ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                if (p.act == ACT_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
                 }
                 if (p.mode == OUT_HEADS) {
                     const int which = n / p.hC;
@@ -203,34 +208,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
                     for (int e = 0; e < 4; ++e) v[e] *= hdst.scale;
                     if (hdst.kind == 0) {          // [B, H, L, DP] row-major per head
                         bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.L + tok) * hdst.DP + dd;
-                        *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                        *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
                     } else {                       // [B, H, DP, L] transposed (keys contiguous)
                         bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.DP + dd) * hdst.L + tok;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dst[(size_t)e * hdst.L] = f2bf(v[e]);
+                        for (int e = 0; e < 4; ++e) dst[(size_t)e * hdst.L] = E::fromf(v[e]);
                     }
                 } else if (p.act == ACT_GEGLU) {   // interleaved (value, gate) channel pairs
                     const float o0 = v[0] * gelu_erf_f(v[1]);
                     const float o1 = v[2] * gelu_erf_f(v[3]);
                     bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + (n >> 1);
-                    *reinterpret_cast<uint32_t*>(dst) = pack_bf2(o0, o1);
+                    *reinterpret_cast<uint32_t*>(dst) = E::pack2(o0, o1);
                 } else if (p.out_f32) {
                     float* dst = reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n;
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n;
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <bool F16, int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     constexpr int lds = 2 * (BM + BN) * (BK * 2 + 16);
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<BM, BN, BK, WM, WN>;
+    auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -258,10 +263,12 @@ int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s) {
     if (p.taps != 1 && p.taps != 9) return imd_set_error("conv_gemm: taps must be 1 or 9 (got %d)", p.taps);
     if (p.K != p.taps * p.Cin) return imd_set_error("conv_gemm: K (%d) != taps*Cin (%d)", p.K, p.taps * p.Cin);
     if (cfg < 0) cfg = imd_conv_gemm_choose_cfg(p.M, p.N);
+    if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("conv_gemm: unknown dtype %d", p.dtype);
+    const bool h = p.dtype == IMD_DTYPE_F16;
     switch (cfg) {
-        case 0: return launch_cfg<128, 128, 64, 2, 2>(p, s);
-        case 1: return launch_cfg<256, 64, 32, 4, 1>(p, s);
-        case 2: return launch_cfg<64, 64, 64, 2, 2>(p, s);
+        case 0: return h ? launch_cfg<true, 128, 128, 64, 2, 2>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2>(p, s);
+        case 1: return h ? launch_cfg<true, 256, 64, 32, 4, 1>(p, s) : launch_cfg<false, 256, 64, 32, 4, 1>(p, s);
+        case 2: return h ? launch_cfg<true, 64, 64, 64, 2, 2>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2>(p, s);
         default: return imd_set_error("conv_gemm: unknown tile config %d", cfg);
     }
 }

@@ -16,6 +16,7 @@
 
 namespace {
 
+template <bool F16>
 __global__ __launch_bounds__(256) void ddim_cfg_step_kernel(const DdimParams p) {
     const long total = (long)p.B * p.HW;                   // one thread per pixel (4 channels = 16 B)
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(256) void ddim_cfg_step_kernel(const DdimParams p) 
         }
         reinterpret_cast<float4*>(p.z)[i] = make_float4(zz[0], zz[1], zz[2], zz[3]);
         if (p.x_next) {
-            const uint4 o = make_uint4(pack_bf2(zz[0], zz[1]), pack_bf2(zz[2], zz[3]), 0u, 0u);
+            const uint4 o = make_uint4(El<F16>::pack2(zz[0], zz[1]), El<F16>::pack2(zz[2], zz[3]), 0u, 0u);
             reinterpret_cast<uint4*>(p.x_next)[i] = o;
             reinterpret_cast<uint4*>(p.x_next)[i + total] = o;
         }
@@ -67,6 +68,7 @@ __global__ void timestep_embedding_kernel(const float* t, float* out, int B, int
 }
 
 // out[r, c] = a[r, c] + b_scale * b[r, c]   (strided rows; 8 channels per thread)
+template <bool F16>
 __global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld,
                                                    long rows, int C, float b_scale) {
     const int vpr = C / 8;
@@ -75,11 +77,11 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, int a_ld, con
         const long r = i / vpr;
         const int c = (int)(i - r * vpr) * 8;
         float fa[8], fb[8];
-        unpack8(*reinterpret_cast<const uint4*>(a + r * a_ld + c), fa);
-        unpack8(*reinterpret_cast<const uint4*>(b + r * b_ld + c), fb);
+        unpack8<F16>(*reinterpret_cast<const uint4*>(a + r * a_ld + c), fa);
+        unpack8<F16>(*reinterpret_cast<const uint4*>(b + r * b_ld + c), fb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) fa[e] += b_scale * fb[e];
-        *reinterpret_cast<uint4*>(out + r * out_ld + c) = pack8(fa);
+        *reinterpret_cast<uint4*>(out + r * out_ld + c) = pack8<F16>(fa);
     }
 }
 
@@ -93,8 +95,9 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const bf16_t* a, int a_ld, 
     }
 }
 
-__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* a, bf16_t* out, long n) {
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = f2bf(a[i]);
+template <bool F16>
+__global__ __launch_bounds__(256) void f32_to_16_kernel(const float* a, bf16_t* out, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = El<F16>::fromf(a[i]);
 }
 
 inline unsigned grid_for(long work_items) {
@@ -109,7 +112,9 @@ inline unsigned grid_for(long work_items) {
 int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s) {
     if (p.B <= 0 || p.HW <= 0) return imd_set_error("ddim_cfg_step: empty latent");
     if (p.mask && (!p.z_img || !p.noise)) return imd_set_error("ddim_cfg_step: inpaint mask given without image latents / noise");
-    hipLaunchKernelGGL(ddim_cfg_step_kernel, dim3(grid_for((long)p.B * p.HW)), dim3(256), 0, s, p);
+    if (p.dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(ddim_cfg_step_kernel<true>, dim3(grid_for((long)p.B * p.HW)), dim3(256), 0, s, p);
+    else if (p.dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(ddim_cfg_step_kernel<false>, dim3(grid_for((long)p.B * p.HW)), dim3(256), 0, s, p);
+    else return imd_set_error("ddim_cfg_step: unknown dtype %d", p.dtype);
     return imd_check_launch("ddim_cfg_step");
 }
 
@@ -120,10 +125,12 @@ int imd_launch_timestep_embedding(const float* t, float* out, int B, int dim, hi
     return imd_check_launch("timestep_embedding");
 }
 
-int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, hipStream_t s) {
+int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, int dtype, hipStream_t s) {
     if (rows <= 0 || C <= 0) return imd_set_error("add: empty tensor");
     if (C % 8 || a_ld % 8 || b_ld % 8 || out_ld % 8) return imd_set_error("add: C and row strides must be multiples of 8");
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale);
+    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(add_kernel<true>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale);
+    else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(add_kernel<false>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale);
+    else return imd_set_error("add: unknown dtype %d", dtype);
     return imd_check_launch("add");
 }
 
@@ -134,8 +141,10 @@ int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long r
     return imd_check_launch("copy2d");
 }
 
-int imd_launch_f32_to_bf16(const float* a, bf16_t* out, long n, hipStream_t s) {
-    if (n <= 0) return imd_set_error("f32_to_bf16: empty tensor");
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, out, n);
-    return imd_check_launch("f32_to_bf16");
+int imd_launch_f32_to_16(const float* a, bf16_t* out, long n, int dtype, hipStream_t s) {
+    if (n <= 0) return imd_set_error("f32_to_16: empty tensor");
+    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(f32_to_16_kernel<true>, dim3(grid_for(n)), dim3(256), 0, s, a, out, n);
+    else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(f32_to_16_kernel<false>, dim3(grid_for(n)), dim3(256), 0, s, a, out, n);
+    else return imd_set_error("f32_to_16: unknown dtype %d", dtype);
+    return imd_check_launch("f32_to_16");
 }

@@ -14,7 +14,7 @@ typedef imd_groupnorm_params GroupNormParams;
 typedef imd_layernorm_params LayerNormParams;
 typedef imd_ddim_params DdimParams;
 
-enum { ACT_NONE = IMD_ACT_NONE, ACT_SILU = IMD_ACT_SILU, ACT_GEGLU = IMD_ACT_GEGLU };
+enum { ACT_NONE = IMD_ACT_NONE, ACT_SILU = IMD_ACT_SILU, ACT_GEGLU = IMD_ACT_GEGLU, ACT_GELU = IMD_ACT_GELU };
 enum { OUT_ROWMAJOR = IMD_OUT_ROWMAJOR, OUT_HEADS = IMD_OUT_HEADS };
 
 // error plumbing (thread-local message, surfaced by imd_last_error())
@@ -30,6 +30,6 @@ int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s);
 int imd_launch_layernorm(const LayerNormParams& p, hipStream_t s);
 int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s);
 int imd_launch_timestep_embedding(const float* t, float* out, int B, int dim, hipStream_t s);
-int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, hipStream_t s);
+int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, int dtype, hipStream_t s);
 int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C, hipStream_t s);
-int imd_launch_f32_to_bf16(const float* a, bf16_t* out, long n, hipStream_t s);
+int imd_launch_f32_to_16(const float* a, bf16_t* out, long n, int dtype, hipStream_t s);

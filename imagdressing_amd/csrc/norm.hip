@@ -20,6 +20,7 @@ constexpr int GN_PIX_PER_CHUNK = 64;
 __device__ __forceinline__ int gn_chunks(int HW) { return (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK; }
 
 // One thread: vector column `vec` (channels 8*vec .. 8*vec+7), pixel lanes interleaved.
+template <bool F16>
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormParams p) {
     __shared__ float red[GN_THREADS][4];
     const int vpp = p.C / 8;                       // vectors per pixel
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormPar
             for (int pix = pix0 + my_pl; pix < pix1; pix += plan) {
                 const uint4 v = *reinterpret_cast<const uint4*>(p.x + ((size_t)b * p.HW + pix) * p.x_ld + c0);
                 float f[8];
-                unpack8(v, f);
+                unpack8<F16>(v, f);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormPar
     }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormParams p) {
     __shared__ float s_mean[64], s_rstd[64];
     const int vpp = p.C / 8;
@@ -121,20 +123,21 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormPar
         for (int pix = pix0 + my_pl; pix < pix1; pix += plan) {
             const uint4 v = *reinterpret_cast<const uint4*>(p.x + ((size_t)b * p.HW + pix) * p.x_ld + c0);
             float f[8];
-            unpack8(v, f);
+            unpack8<F16>(v, f);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float y = f[e] * a[e] + sh[e];
                 if (p.silu) y = silu_f(y);
                 f[e] = y;
             }
-            *reinterpret_cast<uint4*>(p.y + ((size_t)b * p.HW + pix) * p.y_ld + c0) = pack8(f);
+            *reinterpret_cast<uint4*>(p.y + ((size_t)b * p.HW + pix) * p.y_ld + c0) = pack8<F16>(f);
         }
     }
 }
 
 // One wave per row; C <= 8 * 64 * LN_MAXV.
 constexpr int LN_MAXV = 4;
+template <bool F16>
 __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
         const int v = lane + i * 64;
         if (v < nv) {
             const uint4 x = *reinterpret_cast<const uint4*>(p.x + (size_t)row * p.x_ld + v * 8);
-            unpack8(x, f[i]);
+            unpack8<F16>(x, f[i]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += f[i][e];
         }
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
             float y[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = (f[i][e] - mean) * rstd * p.gamma[v * 8 + e] + p.beta[v * 8 + e];
-            *reinterpret_cast<uint4*>(p.y + (size_t)row * p.y_ld + v * 8) = pack8(y);
+            *reinterpret_cast<uint4*>(p.y + (size_t)row * p.y_ld + v * 8) = pack8<F16>(y);
         }
     }
 }
@@ -193,10 +196,14 @@ int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
     if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("groupnorm: pixel strides must be multiples of 8");
     const int chunks = (p.HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK;
     dim3 grid(chunks, p.B);
-    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, s, p);
+    if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("groupnorm: unknown dtype %d", p.dtype);
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    if (h) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, p);
+    else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, p);
     int rc = imd_check_launch("groupnorm stats");
     if (rc) return rc;
-    hipLaunchKernelGGL(gn_apply_kernel, grid, dim3(GN_THREADS), 0, s, p);
+    if (h) hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_THREADS), 0, s, p);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(GN_THREADS), 0, s, p);
     return imd_check_launch("groupnorm apply");
 }
 
@@ -204,6 +211,8 @@ int imd_launch_layernorm(const LayerNormParams& p, hipStream_t s) {
     if (p.rows <= 0) return imd_set_error("layernorm: no rows");
     if (p.C % 8 || p.C > 8 * 64 * LN_MAXV) return imd_set_error("layernorm: C (%d) must be a multiple of 8 and <= %d", p.C, 8 * 64 * LN_MAXV);
     if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("layernorm: row strides must be multiples of 8");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("layernorm: unknown dtype %d", p.dtype);
+    if (p.dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(layernorm_kernel<true>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, dim3((p.rows + 3) / 4), dim3(256), 0, s, p);
     return imd_check_launch("layernorm");
 }

@@ -1,0 +1,101 @@
+"""Multi-GPU: one process per GPU, images sharded over ranks, ONE collective per garment.
+
+The reference has no inference parallelism (batch_size = 1 hard-coded,
+/root/reference/dressing_sd/pipelines/IMAGDressing_v1_pipeline.py:389).  Images of a batch are
+independent given the garment features, so the batch shards over ranks with no data-path collective
+inside the loop.  The only exchange is the step-invariant garment feature set (16 post-LayerNorm
+token matrices, 23.1 MB bf16 at 512x512): rank 0 runs the garment UNet and broadcasts ONE packed
+buffer (RCCL ``ncclBroadcast`` over xGMI; backend "nccl" on ROCm is RCCL, "gloo" on CPU for tests).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_bounds(n: int, r: int = None, w: int = None) -> Tuple[int, int]:
+    """Contiguous block partition of n items: the first n % w ranks get one extra."""
+    r = rank() if r is None else r
+    w = world_size() if w is None else w
+    base, extra = divmod(n, w)
+    lo = r * base + min(r, extra)
+    return lo, lo + base + (1 if r < extra else 0)
+
+
+def shard_rows(t: torch.Tensor) -> torch.Tensor:
+    lo, hi = shard_bounds(t.shape[0])
+    return t[lo:hi]
+
+
+def pack_features(feats: Dict[str, torch.Tensor], names: List[str]) -> Tuple[torch.Tensor, List[Tuple[str, tuple]]]:
+    """Flatten the named tensors (in ``names`` order) into one contiguous buffer + a layout table."""
+    layout = [(n, tuple(feats[n].shape)) for n in names]
+    flat = torch.cat([feats[n].reshape(-1) for n in names]) if names else torch.empty(0)
+    return flat.contiguous(), layout
+
+
+def unpack_features(flat: torch.Tensor, layout: List[Tuple[str, tuple]]) -> Dict[str, torch.Tensor]:
+    out, off = {}, 0
+    for name, shape in layout:
+        n = 1
+        for s in shape:
+            n *= s
+        out[name] = flat[off:off + n].view(shape)
+        off += n
+    return out
+
+
+def feature_layout(unet_like, ref_hw: Tuple[int, int]) -> List[Tuple[str, tuple]]:
+    """Shapes of the garment features every rank can derive locally (no metadata exchange): one
+    [1, M_l, C_l] entry per attention layer of the garment UNet, for a garment latent of ref_hw."""
+    cfg = unet_like.cfg
+    boc = cfg["block_out_channels"]
+    h, w = ref_hw
+    layout = []
+    level_of = {}
+    for i, ch in enumerate(boc):
+        level_of[f"down_blocks.{i}"] = (ch, (h >> i) * (w >> i))
+    rev = list(reversed(boc))
+    for i, ch in enumerate(rev):
+        lv = len(boc) - 1 - i
+        level_of[f"up_blocks.{i}"] = (ch, (h >> lv) * (w >> lv))
+    level_of["mid_block"] = (boc[-1], (h >> (len(boc) - 1)) * (w >> (len(boc) - 1)))
+    for name in unet_like.attn_processors.keys():
+        key = name.split(".attentions")[0]
+        ch, tokens = level_of[key]
+        layout.append((name, (1, tokens, ch)))
+    return layout
+
+
+def broadcast_packed(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
+@torch.no_grad()
+def garment_features_broadcast(pipe, ref_latents: torch.Tensor, cloth_tokens: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Rank 0 computes the garment features; everyone receives them in one broadcast."""
+    runet = pipe.reference_unet
+    hw = (ref_latents.shape[-2], ref_latents.shape[-1])
+    layout = [e for e in feature_layout(runet, hw) if e[0].endswith("attn1.processor")]   # only attn1 is consumed
+    names = [n for n, _ in layout]
+    total = sum(s[1] * s[2] for _, s in layout)
+    if rank() == 0:
+        feats = pipe.garment_features(ref_latents, cloth_tokens)
+        flat, lay0 = pack_features({n: feats[n].to(runet.dtype) for n in names}, names)
+        assert lay0 == layout, "garment feature layout mismatch"
+    else:
+        flat = torch.empty(total, dtype=runet.dtype, device=pipe.device)
+    broadcast_packed(flat, 0)
+    return unpack_features(flat, layout)

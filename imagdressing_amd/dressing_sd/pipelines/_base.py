@@ -1,0 +1,248 @@
+"""Shared machinery of the four ``IMAGDressing_v1`` pipeline classes.
+
+The reference pipelines subclass diffusers' ``StableDiffusionPipeline`` /
+``StableDiffusionControlNetInpaintPipeline`` (un-vendored).  Here the pipeline is a plain class that
+keeps the reference's constructor kwargs, ``__call__`` kwargs, ``set_scale`` / ``set_ipa_scale`` and
+return type, and re-designs the loop (IMAGDressing_v1_pipeline.py:463-541) MI355X-first:
+
+* the reference issues two batch-1 UNet calls per step (cond with garment tokens, uncond without);
+  here ONE UNet call runs a [2B] batch -- rows [0, B) cond, rows [B, 2B) uncond -- with the garment
+  branch switched per row (``sa_batch_mask``), for B images that share the garment;
+* garment features are harvested once per garment from the garment UNet run at batch 1 (the
+  reference runs it at batch 2 and discards half, quirk 8 of SURVEY.md), and their K/V projections
+  are cached inside the processors for the whole loop;
+* CFG + DDIM step + (inpaint blend) + the next step's UNet input are one elementwise kernel over
+  an fp32 latent state;
+* under ``torch.distributed`` the B images are sharded over ranks and the garment features are
+  broadcast from rank 0 (one collective per garment, none in the loop).
+
+Encoders outside the hot path (CLIP text / vision, VAE -- SURVEY.md 8f "next") are duck-typed torch
+modules supplied by the caller, or bypassed with pre-computed tensors (``prompt_embeds``,
+``negative_prompt_embeds``, ``ref_clip_hidden_states``, ``ref_image_latents``, ``latents``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import torch
+
+from ... import ops
+from ...adapter.attention_processor import (IPAttnProcessor2_0, LoRAIPAttnProcessor2_0, LoraRefSAttnProcessor2_0,
+                                            RefSAttnProcessor2_0)
+from ...unet import nchw_to_nhwc8
+
+bf16 = torch.bfloat16
+
+
+@dataclass
+class StableDiffusionPipelineOutput:
+    images: Any
+    nsfw_content_detected: Optional[List[bool]] = None
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
+    """diffusers ``randn_tensor``: CPU generators sample on the CPU (cross-vendor reproducible)."""
+    device = torch.device(device or "cpu")
+    if isinstance(generator, (list, tuple)):
+        return torch.cat([randn_tensor((1,) + tuple(shape[1:]), g, device, dtype) for g in generator], 0)
+    gdev = generator.device if generator is not None else device
+    if gdev.type != device.type:
+        return torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+
+class PipelineBase:
+    vae_scale_factor = 8
+
+    def _init_common(self, *, vae, reference_unet, unet, tokenizer, text_encoder, image_encoder, ImgProj, scheduler,
+                     safety_checker=None, feature_extractor=None, controlnet=None):
+        self.vae, self.reference_unet, self.unet = vae, reference_unet, unet
+        self.tokenizer, self.text_encoder, self.image_encoder = tokenizer, text_encoder, image_encoder
+        self.ImgProj, self.scheduler, self.controlnet = ImgProj, scheduler, controlnet
+        # the reference scripts pass the *classes* here (inference_IMAGdressing.py:133-134): tolerated, unused
+        self.safety_checker, self.feature_extractor = safety_checker, feature_extractor
+        self._cross_attention_kwargs = None
+        self._garment_cache = None
+        if vae is not None and hasattr(vae, "config") and hasattr(vae.config, "block_out_channels"):
+            self.vae_scale_factor = 2 ** (len(vae.config.block_out_channels) - 1)
+
+    # ---- reference surface ----
+    @property
+    def cross_attention_kwargs(self):
+        return self._cross_attention_kwargs
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    _execution_device = device
+
+    def enable_vae_slicing(self):
+        self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        self.vae.disable_slicing()
+
+    def progress_bar(self, iterable=None, total=None):
+        try:
+            from tqdm.auto import tqdm
+            return tqdm(iterable, total=total, disable=getattr(self, "_progress_disabled", True))
+        except Exception:   # pragma: no cover
+            class _N:
+                def __enter__(s): return s
+                def __exit__(s, *a): return False
+                def update(s, *a): pass
+            return _N()
+
+    def set_progress_bar_config(self, disable=False, **kw):
+        self._progress_disabled = disable
+
+    # ---- encoders outside the hot path (duck-typed torch modules) ----
+    def encode_prompt(self, prompt, device, num_images_per_prompt=1, do_classifier_free_guidance=True,
+                      negative_prompt=None, prompt_embeds=None, negative_prompt_embeds=None, lora_scale=None, clip_skip=None):
+        def enc(text):
+            if self.tokenizer is None or self.text_encoder is None:
+                raise ValueError("no tokenizer/text_encoder: pass prompt_embeds / negative_prompt_embeds")
+            ids = self.tokenizer(text, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                                 return_tensors="pt").input_ids
+            return self.text_encoder(ids.to(device))[0]
+        if prompt_embeds is None:
+            prompt_embeds = enc(prompt)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt_embeds = enc(negative_prompt if negative_prompt is not None else "")
+        return prompt_embeds, negative_prompt_embeds
+
+    def _clip_hidden(self, clip_image, device):
+        dt = next(self.image_encoder.parameters()).dtype
+        return self.image_encoder(clip_image.to(device, dtype=dt), output_hidden_states=True).hidden_states[-2]
+
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, dtype, device, generator, latents=None):
+        # NB the reference passes (width, height) in this order to a (height, width) signature, and so keeps
+        # shape [B, 4, width//8, height//8] semantics consistent with its own call (:440-448); we take them named.
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=torch.float32)
+        return latents.to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
+
+    # ---- garment features (A2 of SURVEY 8a) ----
+    @torch.no_grad()
+    def garment_features(self, ref_image_latents: torch.Tensor, cloth_proj_embed: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Garment UNet once at t = 0 with the 16 resampler tokens as context; returns the (post-LayerNorm)
+        input of every attention layer, [1, M, C] each (IMAGDressing_v1_pipeline.py:465-480)."""
+        dt = self.reference_unet.dtype
+        x = nchw_to_nhwc8(ref_image_latents[:1].to(self.device), dt)
+        ehs = cloth_proj_embed[-1:].to(device=self.device, dtype=dt).contiguous()     # the cond half ([1] of the CFG pair)
+        self.reference_unet.forward_nhwc(x, 0, ehs)
+        out = {}
+        for name, proc in self.reference_unet.attn_processors.items():
+            out[name] = proc.cache["hidden_states"]
+        return out
+
+    # ---- the loop ----
+    @torch.no_grad()
+    def denoise(self, *, latents: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: torch.Tensor,
+                sa_hidden_states: Dict[str, torch.Tensor], num_inference_steps: int, guidance_scale: float,
+                control: Optional[dict] = None, inpaint: Optional[dict] = None,
+                callback: Optional[Callable] = None, callback_steps: int = 1, trace: Optional[list] = None) -> torch.Tensor:
+        """latents [B, 4, h, w] fp32 -> final latents [B, 4, h, w] fp32.
+
+        ``control`` = dict(image=[1|B, 3, H, W] in [0,1] or NHWC8 bf16, prompt_embeds=[1,77,768],
+        negative_prompt_embeds=[1,77,768], scale=float, keep=[float]*steps)
+        ``inpaint`` = dict(mask=[B|1,1,h,w], image_latents=[B|1,4,h,w], noise=[B,4,h,w])
+        """
+        dev = self.device
+        B, Cl, h, w = latents.shape
+        HW = h * w
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps, device=dev)
+        timesteps = [int(t) for t in sch.timesteps]
+        z = latents.to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1).reshape(B, HW, Cl).contiguous()
+        dt = self.unet.dtype
+        x_in = torch.zeros(2 * B, h, w, 8, dtype=dt, device=dev)
+        x_in[..., :Cl] = torch.cat([z, z]).view(2 * B, h, w, Cl)
+        # rows [0,B): prompt (+garment), rows [B,2B): negative prompt, no garment -> ehs rows shared per half
+        ehs = torch.cat([prompt_embeds[:1], negative_prompt_embeds[:1]]).to(device=dev, dtype=dt).contiguous()
+        mask_rows = torch.cat([torch.ones(B), torch.zeros(B)]).to(device=dev, dtype=torch.float32)
+        cak = {"sa_hidden_states": sa_hidden_states, "sa_batch_mask": mask_rows}
+        ctrl_img = ctrl_ehs = None
+        if control is not None:
+            img = control["image"]
+            ctrl_img = img if (img.dim() == 4 and img.shape[-1] == 8 and img.dtype == dt) else nchw_to_nhwc8(img.to(dev), dt)
+            ctrl_ehs = torch.cat([control["prompt_embeds"][:1], control["negative_prompt_embeds"][:1]]).to(device=dev, dtype=dt).contiguous()
+        inp = None
+        if inpaint is not None:
+            def nhwc(t, c):
+                t = t.to(device=dev, dtype=torch.float32)
+                if t.shape[0] != B:
+                    t = t.expand(B, -1, -1, -1)
+                return t.permute(0, 2, 3, 1).reshape(B, HW, c).contiguous()
+            inp = dict(mask=nhwc(inpaint["mask"], 1).view(B, HW).contiguous(), z_img=nhwc(inpaint["image_latents"], Cl),
+                       noise=nhwc(inpaint["noise"], Cl))
+        for i, t in enumerate(timesteps):
+            down = mid = None
+            if control is not None:
+                keep = control.get("keep", [1.0] * len(timesteps))[i]
+                down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, float(control.get("scale", 1.0)) * keep)
+            eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid)
+            kw = {}
+            if inp is not None:
+                a_next = sch.alpha(timesteps[i + 1]) if i < len(timesteps) - 1 else None
+                kw = dict(mask=inp["mask"], z_img=inp["z_img"], noise=inp["noise"], a_next=a_next)
+            ops.ddim_cfg_step(z, eps, x_in.view(2 * B, HW, 8), guidance=float(guidance_scale), a_t=sch.alpha(t),
+                              a_prev=sch.alpha_prev(t), **kw)
+            if trace is not None:
+                trace.append(z.clone())
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, z.view(B, h, w, Cl).permute(0, 3, 1, 2))
+        return z.view(B, h, w, Cl).permute(0, 3, 1, 2).contiguous()
+
+    # ---- shared front / back end ----
+    def _cloth_tokens(self, ref_clip_image, ref_clip_hidden_states, device):
+        """(cloth_proj_embed, cloth_null_embeds) [1,16,768] each (:409-415).  The null tokens are computed for
+        API parity only -- the garment UNet's null half is discarded by the reference (:476-480)."""
+        if ref_clip_hidden_states is None:
+            ref_clip_hidden_states = self._clip_hidden(ref_clip_image, device)
+        return self.ImgProj(ref_clip_hidden_states.to(device))
+
+    def _ref_latents(self, ref_image, ref_image_latents):
+        if ref_image_latents is not None:
+            return ref_image_latents
+        p = next(self.vae.parameters())
+        return self.vae.encode(ref_image.to(dtype=p.dtype, device=p.device)).latent_dist.mean * 0.18215   # :457-458
+
+    def _decode(self, latents, output_type, generator=None):
+        if output_type == "latent":
+            return StableDiffusionPipelineOutput(images=latents, nsfw_content_detected=None)
+        p = next(self.vae.parameters())
+        image = self.vae.decode((latents / self.vae.config.scaling_factor).to(p.dtype), return_dict=False)[0]
+        image = (image.float() / 2 + 0.5).clamp(0, 1)
+        if output_type == "pt":
+            return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None)
+        arr = (image.permute(0, 2, 3, 1).cpu().numpy() * 255).round().astype("uint8")
+        if output_type == "np":
+            return StableDiffusionPipelineOutput(images=arr, nsfw_content_detected=None)
+        from PIL import Image
+        return StableDiffusionPipelineOutput(images=[Image.fromarray(a) for a in arr], nsfw_content_detected=None)
+
+    def _shard(self, latents, shard: bool):
+        """Data-parallel sharding of the image batch over torch.distributed ranks (no-op single process)."""
+        from ... import dist as imd_dist
+        return imd_dist.shard_rows(latents) if shard else latents
+
+    def _sa_states(self, ref_latents, cloth_tokens, shard: bool):
+        from ... import dist as imd_dist
+        if shard and imd_dist.world_size() > 1:
+            return imd_dist.garment_features_broadcast(self, ref_latents, cloth_tokens)
+        return self.garment_features(ref_latents, cloth_tokens)
+
+
+def set_scale_by_type(unet, cls, **attrs):
+    for proc in unet.attn_processors.values():
+        if isinstance(proc, cls):
+            for k, v in attrs.items():
+                setattr(proc, k, v)
+
+
+__all__ = ["PipelineBase", "StableDiffusionPipelineOutput", "randn_tensor", "set_scale_by_type",
+           "RefSAttnProcessor2_0", "LoraRefSAttnProcessor2_0", "LoRAIPAttnProcessor2_0", "IPAttnProcessor2_0"]

@@ -139,22 +139,27 @@ def controlnet_param_shapes(cfg=None, cond_channels=3, embed_channels=(16, 32, 9
 
 
 def random_state_dict(shapes: Dict[str, tuple], seed: int, device="cpu", dtype=torch.float32, zero_convs=False):
-    """Seeded synthetic weights with fan-in scaling (keeps activations O(1)); norm weights ~ 1."""
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    """Seeded synthetic weights with fan-in scaling (keeps activations O(1)); norm weights ~ 1.
+    Generated on ``device`` (a CPU generator gives streams that are identical on every host)."""
+    device = torch.device(device)
+    g = torch.Generator(device=device).manual_seed(seed)
+
+    def randn(shape):
+        return torch.randn(shape, generator=g, device=device)
     sd = {}
     for name, shape in shapes.items():
         if name.endswith(".bias"):
-            t = torch.randn(shape, generator=g) * 0.02
+            t = randn(shape) * 0.02
         elif ".norm" in name or name.startswith("conv_norm_out"):
-            t = 1.0 + torch.randn(shape, generator=g) * 0.05
+            t = 1.0 + randn(shape) * 0.05
         else:
             fan_in = 1
             for d in shape[1:]:
                 fan_in *= d
-            t = torch.randn(shape, generator=g) * (1.0 / math.sqrt(fan_in))
+            t = randn(shape) * (1.0 / math.sqrt(fan_in))
             if zero_convs and name.startswith(("controlnet_down_blocks", "controlnet_mid_block")):
                 t = t * 0.1
-        sd[name] = t.to(device=device, dtype=dtype)
+        sd[name] = t.to(dtype=dtype)
     return sd
 
 
@@ -168,20 +173,20 @@ def _f32(t, device):
 class LinearOp:
     """Packed ``nn.Linear``: weight [N, K] bf16 in HBM, bias fp32.  Callable on [..., K] tensors."""
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], device):
-        self.weight = weight.detach().to(device=device, dtype=bf16).contiguous()
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], device, dtype=bf16):
+        self.weight = weight.detach().to(device=device, dtype=dtype).contiguous()
         self.bias = None if bias is None else _f32(bias, device)
         self.out_features, self.in_features = self.weight.shape
 
     def __call__(self, x: torch.Tensor, **kw) -> torch.Tensor:
-        x2 = x.to(bf16).contiguous().view(-1, self.in_features)
+        x2 = x.to(self.weight.dtype).contiguous().view(-1, self.in_features)
         return ops.linear(x2, self.weight, self.bias, **kw).view(*x.shape[:-1], self.out_features)
 
 
 class ConvOp:
     """Packed conv: weight [Cout][ky][kx][Cin_padded] bf16."""
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], device):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], device, dtype=bf16):
         cout, cin, kh, kw = weight.shape
         assert (kh, kw) in ((1, 1), (3, 3))
         cin_p = (cin + 7) // 8 * 8
@@ -189,7 +194,7 @@ class ConvOp:
         if cin_p != cin:
             w = torch.nn.functional.pad(w, (0, cin_p - cin))
         cout_p = (cout + 3) // 4 * 4
-        self.weight = w.reshape(cout, kh * kw * cin_p).to(bf16).contiguous()
+        self.weight = w.reshape(cout, kh * kw * cin_p).to(dtype).contiguous()
         self.bias = None if bias is None else _f32(bias, device)
         self.cin, self.cin_p, self.cout, self.taps = cin, cin_p, cout, kh * kw
         assert cout_p == cout, "output channels must be a multiple of 4"
@@ -213,12 +218,13 @@ class Attention:
     """Attribute surface of diffusers ``Attention`` that processors read
     (adapter/attention_processor.py:545-625): heads, to_q/to_k/to_v, to_out[0] (+bias), to_out[1]."""
 
-    def __init__(self, sd, prefix, heads, device):
+    def __init__(self, sd, prefix, heads, device, dtype=bf16):
         self.heads = heads
-        self.to_q = LinearOp(sd[f"{prefix}.to_q.weight"], None, device)
-        self.to_k = LinearOp(sd[f"{prefix}.to_k.weight"], None, device)
-        self.to_v = LinearOp(sd[f"{prefix}.to_v.weight"], None, device)
-        self.to_out = [LinearOp(sd[f"{prefix}.to_out.0.weight"], sd[f"{prefix}.to_out.0.bias"], device), _Identity()]
+        self.dtype = dtype
+        self.to_q = LinearOp(sd[f"{prefix}.to_q.weight"], None, device, dtype)
+        self.to_k = LinearOp(sd[f"{prefix}.to_k.weight"], None, device, dtype)
+        self.to_v = LinearOp(sd[f"{prefix}.to_v.weight"], None, device, dtype)
+        self.to_out = [LinearOp(sd[f"{prefix}.to_out.0.weight"], sd[f"{prefix}.to_out.0.bias"], device, dtype), _Identity()]
         self.query_dim = self.to_q.out_features
         self.is_cross = self.to_k.in_features != self.query_dim
         self.spatial_norm = None
@@ -251,24 +257,24 @@ class Attention:
                         imd_residual=residual, **cross_attention_kwargs)
         out = proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=None,
                    **cross_attention_kwargs)
-        out = out.to(bf16).contiguous()
+        out = out.to(self.dtype).contiguous()
         return out if residual is None else ops.add(out, residual)
 
 
 class TransformerBlock:
-    def __init__(self, sd, p, ch, heads, device):
+    def __init__(self, sd, p, ch, heads, device, dtype=bf16):
         self.norm1 = NormParams(sd, f"{p}.norm1", device)
         self.norm2 = NormParams(sd, f"{p}.norm2", device)
         self.norm3 = NormParams(sd, f"{p}.norm3", device)
-        self.attn1 = Attention(sd, f"{p}.attn1", heads, device)
-        self.attn2 = Attention(sd, f"{p}.attn2", heads, device)
+        self.attn1 = Attention(sd, f"{p}.attn1", heads, device, dtype)
+        self.attn2 = Attention(sd, f"{p}.attn2", heads, device, dtype)
         # GEGLU: interleave (value_j, gate_j) rows so a lane holds both halves of a pair
         w, b = sd[f"{p}.ff.net.0.proj.weight"], sd[f"{p}.ff.net.0.proj.bias"]
         inner = w.shape[0] // 2
         wi = torch.stack([w[:inner], w[inner:]], dim=1).reshape(2 * inner, w.shape[1])
         bi = torch.stack([b[:inner], b[inner:]], dim=1).reshape(2 * inner)
-        self.ff_in = LinearOp(wi, bi, device)
-        self.ff_out = LinearOp(sd[f"{p}.ff.net.2.weight"], sd[f"{p}.ff.net.2.bias"], device)
+        self.ff_in = LinearOp(wi, bi, device, dtype)
+        self.ff_out = LinearOp(sd[f"{p}.ff.net.2.weight"], sd[f"{p}.ff.net.2.bias"], device, dtype)
 
     def __call__(self, h, ehs, cak):
         n = ops.layer_norm(h, self.norm1.weight, self.norm1.bias)
@@ -282,11 +288,11 @@ class TransformerBlock:
 
 
 class Transformer2D:
-    def __init__(self, sd, p, ch, heads, groups, device):
+    def __init__(self, sd, p, ch, heads, groups, device, dtype=bf16):
         self.norm = NormParams(sd, f"{p}.norm", device)
-        self.proj_in = ConvOp(sd[f"{p}.proj_in.weight"], sd[f"{p}.proj_in.bias"], device)
-        self.proj_out = ConvOp(sd[f"{p}.proj_out.weight"], sd[f"{p}.proj_out.bias"], device)
-        self.transformer_blocks = [TransformerBlock(sd, f"{p}.transformer_blocks.0", ch, heads, device)]
+        self.proj_in = ConvOp(sd[f"{p}.proj_in.weight"], sd[f"{p}.proj_in.bias"], device, dtype)
+        self.proj_out = ConvOp(sd[f"{p}.proj_out.weight"], sd[f"{p}.proj_out.bias"], device, dtype)
+        self.transformer_blocks = [TransformerBlock(sd, f"{p}.transformer_blocks.0", ch, heads, device, dtype)]
         self.groups = groups
 
     def __call__(self, x, ehs, cak):
@@ -299,14 +305,14 @@ class Transformer2D:
 
 
 class ResnetBlock:
-    def __init__(self, sd, p, groups, device, temb_slices: list):
+    def __init__(self, sd, p, groups, device, temb_slices: list, dtype=bf16):
         self.norm1 = NormParams(sd, f"{p}.norm1", device)
         self.norm2 = NormParams(sd, f"{p}.norm2", device)
-        self.conv1 = ConvOp(sd[f"{p}.conv1.weight"], sd[f"{p}.conv1.bias"], device)
-        self.conv2 = ConvOp(sd[f"{p}.conv2.weight"], sd[f"{p}.conv2.bias"], device)
+        self.conv1 = ConvOp(sd[f"{p}.conv1.weight"], sd[f"{p}.conv1.bias"], device, dtype)
+        self.conv2 = ConvOp(sd[f"{p}.conv2.weight"], sd[f"{p}.conv2.bias"], device, dtype)
         self.shortcut = None
         if f"{p}.conv_shortcut.weight" in sd:
-            self.shortcut = ConvOp(sd[f"{p}.conv_shortcut.weight"], sd[f"{p}.conv_shortcut.bias"], device)
+            self.shortcut = ConvOp(sd[f"{p}.conv_shortcut.weight"], sd[f"{p}.conv_shortcut.bias"], device, dtype)
         self.groups = groups
         # time_emb_proj is executed as part of ONE concatenated GEMM per forward
         self.temb_off = sum(w.shape[0] for w, _ in temb_slices)
@@ -327,32 +333,32 @@ class _Encoder:
         boc = cfg["block_out_channels"]
         g, heads = cfg["norm_num_groups"], cfg["attention_head_dim"]
         self._temb_slices: list = []
-        self.conv_in = ConvOp(sd["conv_in.weight"], sd["conv_in.bias"], device)
-        self.time_lin1 = LinearOp(sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"], device)
-        self.time_lin2 = LinearOp(sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"], device)
+        self.conv_in = ConvOp(sd["conv_in.weight"], sd["conv_in.bias"], device, self.dtype)
+        self.time_lin1 = LinearOp(sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"], device, self.dtype)
+        self.time_lin2 = LinearOp(sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"], device, self.dtype)
         self.down_blocks = []
         self._attn: Dict[str, Attention] = {}
         for i, ch in enumerate(boc):
             blk = SimpleNamespace(resnets=[], attentions=[], downsampler=None)
             for j in range(2):
-                blk.resnets.append(ResnetBlock(sd, f"down_blocks.{i}.resnets.{j}", g, device, self._temb_slices))
+                blk.resnets.append(ResnetBlock(sd, f"down_blocks.{i}.resnets.{j}", g, device, self._temb_slices, self.dtype))
                 if cfg["down_attn"][i]:
                     blk.attentions.append(self._transformer(sd, f"down_blocks.{i}.attentions.{j}", ch, heads, g, device))
             if i != len(boc) - 1:
                 blk.downsampler = ConvOp(sd[f"down_blocks.{i}.downsamplers.0.conv.weight"],
-                                         sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], device)
+                                         sd[f"down_blocks.{i}.downsamplers.0.conv.bias"], device, self.dtype)
             self.down_blocks.append(blk)
 
     def _build_mid(self, sd, cfg, device):
         boc = cfg["block_out_channels"]
         g, heads = cfg["norm_num_groups"], cfg["attention_head_dim"]
         self.mid_block = SimpleNamespace(
-            resnets=[ResnetBlock(sd, "mid_block.resnets.0", g, device, self._temb_slices)],
+            resnets=[ResnetBlock(sd, "mid_block.resnets.0", g, device, self._temb_slices, self.dtype)],
             attentions=[self._transformer(sd, "mid_block.attentions.0", boc[-1], heads, g, device)])
-        self.mid_block.resnets.append(ResnetBlock(sd, "mid_block.resnets.1", g, device, self._temb_slices))
+        self.mid_block.resnets.append(ResnetBlock(sd, "mid_block.resnets.1", g, device, self._temb_slices, self.dtype))
 
     def _transformer(self, sd, p, ch, heads, groups, device):
-        t = Transformer2D(sd, p, ch, heads, groups, device)
+        t = Transformer2D(sd, p, ch, heads, groups, device, self.dtype)
         b = t.transformer_blocks[0]
         self._attn[f"{p}.transformer_blocks.0.attn1.processor"] = b.attn1
         self._attn[f"{p}.transformer_blocks.0.attn2.processor"] = b.attn2
@@ -361,7 +367,7 @@ class _Encoder:
     def _finish_temb(self, device):
         w = torch.cat([w for w, _ in self._temb_slices], dim=0)
         b = torch.cat([b for _, b in self._temb_slices], dim=0)
-        self.temb_proj = LinearOp(w, b, device)
+        self.temb_proj = LinearOp(w, b, device, self.dtype)
         del self._temb_slices
 
     # ---- processors (diffusers API) ----
@@ -386,7 +392,7 @@ class _Encoder:
             t = torch.full((B,), float(timestep), dtype=torch.float32, device=device)
         else:
             t = timestep.to(device=device, dtype=torch.float32).reshape(-1).expand(B).contiguous()
-        e = ops.f32_to_bf16(ops.timestep_embedding(t, self.time_lin1.in_features))
+        e = ops.f32_to_16(ops.timestep_embedding(t, self.time_lin1.in_features), self.dtype)
         e = ops.linear(e, self.time_lin1.weight, self.time_lin1.bias, act=ops.ACT_SILU)
         # every consumer applies SiLU first (ResnetBlock2D.time_emb_proj(nonlinearity(temb))): store silu(temb)
         e = ops.linear(e, self.time_lin2.weight, self.time_lin2.bias, act=ops.ACT_SILU)
@@ -416,17 +422,19 @@ def _default_processor():
     return AttnProcessor2_0()
 
 
-def nchw_to_nhwc8(x: torch.Tensor) -> torch.Tensor:
-    """[B, C<=8, H, W] any float dtype -> [B, H, W, 8] bf16 (zero padded).  Boundary glue only."""
+def nchw_to_nhwc8(x: torch.Tensor, dtype=bf16) -> torch.Tensor:
+    """[B, C<=8, H, W] any float dtype -> [B, H, W, 8] 16-bit (zero padded).  Boundary glue only."""
     B, Cc, H, W = x.shape
-    out = torch.zeros(B, H, W, (Cc + 7) // 8 * 8, dtype=bf16, device=x.device)
+    out = torch.zeros(B, H, W, (Cc + 7) // 8 * 8, dtype=dtype, device=x.device)
     out[..., :Cc] = x.permute(0, 2, 3, 1)
     return out
 
 
 class UNet2DConditionModel(_Encoder):
-    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[dict] = None, device="cuda"):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[dict] = None, device="cuda", dtype=bf16):
         cfg = dict(SD15_CONFIG, **(config or {}))
+        if dtype not in ops.DTYPE_CODE:
+            raise ValueError(f"dtype must be torch.bfloat16 or torch.float16, got {dtype}")
         want = unet_param_shapes(cfg)
         missing = [k for k in want if k not in state_dict]
         if missing:
@@ -437,7 +445,7 @@ class UNet2DConditionModel(_Encoder):
         self.cfg = cfg
         self.config = SimpleNamespace(**cfg)
         self.device = torch.device(device)
-        self.dtype = bf16
+        self.dtype = dtype
         sd, dev = state_dict, self.device
         boc = cfg["block_out_channels"]
         g, heads = cfg["norm_num_groups"], cfg["attention_head_dim"]
@@ -456,24 +464,24 @@ class UNet2DConditionModel(_Encoder):
         for i, ch in enumerate(rev):
             blk = SimpleNamespace(resnets=[], attentions=[], upsampler=None)
             for j in range(3):
-                blk.resnets.append(ResnetBlock(sd, f"up_blocks.{i}.resnets.{j}", g, dev, self._temb_slices))
+                blk.resnets.append(ResnetBlock(sd, f"up_blocks.{i}.resnets.{j}", g, dev, self._temb_slices, self.dtype))
                 if up_attn[i]:
                     blk.attentions.append(self._transformer(sd, f"up_blocks.{i}.attentions.{j}", ch, heads, g, dev))
             if i != len(boc) - 1:
                 blk.upsampler = ConvOp(sd[f"up_blocks.{i}.upsamplers.0.conv.weight"],
-                                       sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], dev)
+                                       sd[f"up_blocks.{i}.upsamplers.0.conv.bias"], dev, self.dtype)
             self.up_blocks.append(blk)
         up_attn_map = self._attn
         self._attn = {**enc_attn, **up_attn_map, **mid_attn}
         self._finish_temb(dev)
         self.conv_norm_out = NormParams(sd, "conv_norm_out", dev)
-        self.conv_out = ConvOp(sd["conv_out.weight"], sd["conv_out.bias"], dev)
+        self.conv_out = ConvOp(sd["conv_out.weight"], sd["conv_out.bias"], dev, self.dtype)
         self.set_attn_processor(_default_processor())
 
     @classmethod
-    def random_init(cls, seed: int = 0, config: Optional[dict] = None, device="cuda"):
+    def random_init(cls, seed: int = 0, config: Optional[dict] = None, device="cuda", dtype=bf16):
         cfg = dict(SD15_CONFIG, **(config or {}))
-        return cls(random_state_dict(unet_param_shapes(cfg), seed), cfg, device)
+        return cls(random_state_dict(unet_param_shapes(cfg), seed, device=device), cfg, device, dtype)
 
     # ------------------------------------------------------------------------------------
     def forward_nhwc(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
@@ -510,16 +518,16 @@ class UNet2DConditionModel(_Encoder):
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 return_dict: bool = False, **unused):
         """diffusers-compatible entry: NCHW in, (NCHW,) out in the input dtype."""
-        x = nchw_to_nhwc8(sample.to(self.device))
+        x = nchw_to_nhwc8(sample.to(self.device), self.dtype)
         B, _, H, W = sample.shape
 
         def res_nhwc(r):
             if r.dim() == 3:               # the reference indexes residuals by batch: down_block[1] (:662-666)
                 r = r.unsqueeze(0)
-            return r.to(device=self.device, dtype=bf16).permute(0, 2, 3, 1).contiguous()
+            return r.to(device=self.device, dtype=self.dtype).permute(0, 2, 3, 1).contiguous()
         dres = None if down_block_additional_residuals is None else [res_nhwc(r) for r in down_block_additional_residuals]
         mres = None if mid_block_additional_residual is None else res_nhwc(mid_block_additional_residual)
-        ehs = encoder_hidden_states.to(device=self.device, dtype=bf16).contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=self.dtype).contiguous()
         eps = self.forward_nhwc(x, timestep, ehs, cross_attention_kwargs, dres, mres)
         out = eps.view(B, H, W, -1).permute(0, 3, 1, 2).to(sample.dtype)
         return (out,)
@@ -531,7 +539,7 @@ class ControlNetModel(_Encoder):
     """SD1.5 ControlNet: encoder copy + conditioning embedding + 13 zero-convs.  Returns NHWC bf16
     residuals (consumed by ``UNet2DConditionModel.forward_nhwc``)."""
 
-    def __init__(self, state_dict, config: Optional[dict] = None, device="cuda"):
+    def __init__(self, state_dict, config: Optional[dict] = None, device="cuda", dtype=bf16):
         cfg = dict(SD15_CONFIG, **(config or {}))
         want = controlnet_param_shapes(cfg)
         missing = [k for k in want if k not in state_dict]
@@ -540,33 +548,33 @@ class ControlNetModel(_Encoder):
         self.cfg = cfg
         self.config = SimpleNamespace(global_pool_conditions=False, **cfg)
         self.device = torch.device(device)
-        self.dtype = bf16
+        self.dtype = dtype
         sd, dev = state_dict, self.device
         self._build_encoder(sd, cfg, dev)
         self._build_mid(sd, cfg, dev)
         self._finish_temb(dev)
         e = "controlnet_cond_embedding"
-        self.cond_convs = [ConvOp(sd[f"{e}.conv_in.weight"], sd[f"{e}.conv_in.bias"], dev)]
+        self.cond_convs = [ConvOp(sd[f"{e}.conv_in.weight"], sd[f"{e}.conv_in.bias"], dev, dtype)]
         self.cond_strides = [1]
         i = 0
         while f"{e}.blocks.{i}.weight" in sd:
-            self.cond_convs.append(ConvOp(sd[f"{e}.blocks.{i}.weight"], sd[f"{e}.blocks.{i}.bias"], dev))
+            self.cond_convs.append(ConvOp(sd[f"{e}.blocks.{i}.weight"], sd[f"{e}.blocks.{i}.bias"], dev, dtype))
             self.cond_strides.append(2 if i % 2 == 1 else 1)
             i += 1
-        self.cond_out = ConvOp(sd[f"{e}.conv_out.weight"], sd[f"{e}.conv_out.bias"], dev)
+        self.cond_out = ConvOp(sd[f"{e}.conv_out.weight"], sd[f"{e}.conv_out.bias"], dev, dtype)
         self.zero_convs = []
         i = 0
         while f"controlnet_down_blocks.{i}.weight" in sd:
-            self.zero_convs.append(ConvOp(sd[f"controlnet_down_blocks.{i}.weight"], sd[f"controlnet_down_blocks.{i}.bias"], dev))
+            self.zero_convs.append(ConvOp(sd[f"controlnet_down_blocks.{i}.weight"], sd[f"controlnet_down_blocks.{i}.bias"], dev, dtype))
             i += 1
-        self.zero_mid = ConvOp(sd["controlnet_mid_block.weight"], sd["controlnet_mid_block.bias"], dev)
+        self.zero_mid = ConvOp(sd["controlnet_mid_block.weight"], sd["controlnet_mid_block.bias"], dev, dtype)
         self.set_attn_processor(_default_processor())
         self._cond_cache = None
 
     @classmethod
-    def random_init(cls, seed: int = 1, config: Optional[dict] = None, device="cuda"):
+    def random_init(cls, seed: int = 1, config: Optional[dict] = None, device="cuda", dtype=bf16):
         cfg = dict(SD15_CONFIG, **(config or {}))
-        return cls(random_state_dict(controlnet_param_shapes(cfg), seed, zero_convs=True), cfg, device)
+        return cls(random_state_dict(controlnet_param_shapes(cfg), seed, device=device, zero_convs=True), cfg, device, dtype)
 
     def cond_embedding(self, cond_nhwc8: torch.Tensor) -> torch.Tensor:
         """controlnet_cond [Bc, H, W, 8] bf16 -> [Bc, H/8, W/8, 320]; step-invariant, cached per image."""
@@ -600,9 +608,9 @@ class ControlNetModel(_Encoder):
                 guess_mode=False, return_dict=False, **unused):
         """diffusers-compatible entry (NCHW in); residuals are returned NHWC-tagged bf16 tensors in
         NCHW *view* order so ``down[i][1]`` style indexing by batch keeps working."""
-        x = nchw_to_nhwc8(sample.to(self.device))
-        cond = nchw_to_nhwc8(controlnet_cond.to(self.device))
-        ehs = encoder_hidden_states.to(device=self.device, dtype=bf16).contiguous()
+        x = nchw_to_nhwc8(sample.to(self.device), self.dtype)
+        cond = nchw_to_nhwc8(controlnet_cond.to(self.device), self.dtype)
+        ehs = encoder_hidden_states.to(device=self.device, dtype=self.dtype).contiguous()
         down, mid = self.forward_nhwc(x, timestep, ehs, cond, float(conditioning_scale))
         return [d.permute(0, 3, 1, 2) for d in down], mid.permute(0, 3, 1, 2)
 

@@ -6,8 +6,8 @@
  * interface it replaces (paths relative to the reference checkout).
  *
  * Conventions
- *   - All pointers are DEVICE pointers into HBM unless stated otherwise; bf16 tensors are passed
- *     as uint16_t*.  Inputs are borrowed and must stay alive until the stream work completes.
+ *   - All pointers are DEVICE pointers into HBM unless stated otherwise; 16-bit tensors (bf16 or fp16, chosen
+ *     per call by `dtype`) are passed as uint16_t*.  Inputs are borrowed and must stay alive until the stream work completes.
  *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); kernels are only
  *     enqueued, never synchronised; no allocation happens inside any call (hipGraph-capturable).
  *   - Return value: 0 on success, non-zero on error; imd_last_error() returns the message
@@ -27,8 +27,10 @@ extern "C" {
 
 #define IMD_ABI_VERSION 1
 
-enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2 };
+enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3 };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
+/* 16-bit element type of activations and weights (both run v_mfma_f32_32x32x16_* at the same rate) */
+enum { IMD_DTYPE_BF16 = 0, IMD_DTYPE_F16 = 1 };
 
 /* destination of one split (Q, K or V) of a head-split projection */
 typedef struct imd_heads_dest {
@@ -57,6 +59,7 @@ typedef struct imd_conv_gemm_params {
     int mode;            /* IMD_OUT_* */
     int hC, hH, hD;      /* head split: channels per split, heads, head dim */
     imd_heads_dest hd[3];
+    int dtype;           /* IMD_DTYPE_* */
 } imd_conv_gemm_params;
 
 typedef struct imd_attn_params {
@@ -71,6 +74,7 @@ typedef struct imd_attn_params {
     int L1, L1P, kv1_bdiv; /* kv batch entry of batch b is b / kv1_bdiv */
     int L2, L2P, kv2_bdiv;
     int out_ld;
+    int dtype;
 } imd_attn_params;
 
 typedef struct imd_groupnorm_params {
@@ -79,12 +83,14 @@ typedef struct imd_groupnorm_params {
     int B, HW, C, G, x_ld, y_ld;
     float eps;
     int silu;
+    int dtype;
 } imd_groupnorm_params;
 
 typedef struct imd_layernorm_params {
     const uint16_t* x; uint16_t* y; const float* gamma; const float* beta;
     int rows, C, x_ld, y_ld;
     float eps;
+    int dtype;
 } imd_layernorm_params;
 
 typedef struct imd_ddim_params {
@@ -97,6 +103,7 @@ typedef struct imd_ddim_params {
     const float* z_img;   /* [B, HW, 4] */
     const float* noise;   /* [B, HW, 4] */
     float sqrt_a_next, sqrt_1m_a_next;
+    int dtype;            /* element type of x_next */
 } imd_ddim_params;
 
 /* library / device */
@@ -138,10 +145,11 @@ int imd_timestep_embedding(const float* t, float* out, int B, int dim, void* str
 
 /* out = a + b_scale * b over [rows, C] with row strides (ControlNet residual add,
  * ..._pipeline_ipa_controlnet.py:676-677,687-688; skip + residual). */
-int imd_add(const uint16_t* a, int a_ld, const uint16_t* b, int b_ld, uint16_t* out, int out_ld, long rows, int C, float b_scale, void* stream);
+int imd_add(const uint16_t* a, int a_ld, const uint16_t* b, int b_ld, uint16_t* out, int out_ld, long rows, int C, float b_scale, int dtype, void* stream);
 /* strided 2-D copy (channel concat of UNet skip connections). */
 int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows, int C, void* stream);
-int imd_f32_to_bf16(const float* a, uint16_t* out, long n, void* stream);
+/* fp32 -> 16-bit element cast (round to nearest even). */
+int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

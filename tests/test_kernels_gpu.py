@@ -10,6 +10,8 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 bf16 = torch.bfloat16
+DTS = pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+TOL = {torch.bfloat16: 1e-2, torch.float16: 2e-3}      # fp16 carries 3 more mantissa bits
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +31,10 @@ def rnd(seed, *shape, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-def assert_close(got, ref, atol=1e-2, rtol=1e-2, what=""):
+def assert_close(got, ref, atol=None, rtol=None, what=""):
+    base = TOL.get(got.dtype, 1e-2)
+    atol = base if atol is None else atol
+    rtol = base if rtol is None else rtol
     got = got.float().cpu()
     ref = ref.float().cpu()
     assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
@@ -49,20 +54,22 @@ def assert_close(got, ref, atol=1e-2, rtol=1e-2, what=""):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg", [0, 1, 2, -1])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 320), (77, 64, 768), (8, 1280, 320), (130, 4, 72)])
-def test_linear(ops, cfg, M, N, K):
-    x = rnd(1, M, K).to(bf16)
-    w = rnd(2, N, K, scale=K ** -0.5).to(bf16)      # asymmetric: catches transposes
+@DTS
+def test_linear(ops, cfg, M, N, K, dt):
+    x = rnd(1, M, K).to(dt)
+    w = rnd(2, N, K, scale=K ** -0.5).to(dt)      # asymmetric: catches transposes
     b = rnd(3, N)
     ref = x.float() @ w.float().t() + b
     out = ops.linear(dev(x), dev(w), dev(b), cfg=cfg)
-    assert out.dtype == bf16
+    assert out.dtype == dt
     assert_close(out, ref, what=f"linear cfg={cfg}")
 
 
-def test_linear_epilogues(ops):
+@DTS
+def test_linear_epilogues(ops, dt):
     M, N, K = 200, 128, 64
-    x = rnd(1, M, K).to(bf16); w = rnd(2, N, K, scale=K ** -0.5).to(bf16); b = rnd(3, N)
-    res = rnd(4, M, N).to(bf16)
+    x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N)
+    res = rnd(4, M, N).to(dt)
     base = x.float() @ w.float().t() + b
     assert_close(ops.linear(dev(x), dev(w), dev(b), res=dev(res)), base + res.float(), what="residual")
     assert_close(ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_SILU), F.silu(base), what="silu")
@@ -75,9 +82,10 @@ def test_linear_epilogues(ops):
     assert_close(g, base[:, 0::2] * F.gelu(base[:, 1::2]), what="geglu")
 
 
-def test_linear_no_bias_large_k(ops):
+@DTS
+def test_linear_no_bias_large_k(ops, dt):
     M, N, K = 512, 1280, 11520
-    x = rnd(5, M, K).to(bf16); w = rnd(6, N, K, scale=K ** -0.5).to(bf16)
+    x = rnd(5, M, K).to(dt); w = rnd(6, N, K, scale=K ** -0.5).to(dt)
     ref = x.float() @ w.float().t()
     assert_close(ops.linear(dev(x), dev(w)), ref, what="large K")
 
@@ -93,9 +101,10 @@ def pack_conv(w):  # [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
     (2, 16, 16, 64, 64, 1, False), (1, 12, 20, 32, 320, 1, False), (2, 16, 16, 64, 128, 2, False),
     (1, 8, 8, 64, 64, 1, True), (1, 9, 7, 8, 320, 1, False), (3, 6, 6, 320, 4, 1, False)])
-def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups):
-    x = rnd(1, B, Cin, H, W).to(bf16)
-    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(bf16)
+@DTS
+def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups, dt):
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
     b = rnd(3, Cout)
     xin = x.float()
     if ups:
@@ -106,10 +115,11 @@ def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups):
     assert_close(out, ref, what=f"conv3x3 cfg={cfg}")
 
 
-def test_conv_epilogue_rowvec_residual_scale(ops):
+@DTS
+def test_conv_epilogue_rowvec_residual_scale(ops, dt):
     B, H, W, Cin, Cout = 2, 8, 8, 64, 128
-    x = rnd(1, B, Cin, H, W).to(bf16); w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(bf16)
-    b = rnd(3, Cout); temb = rnd(4, B, 256); res = rnd(5, B, H, W, Cout).to(bf16)
+    x = rnd(1, B, Cin, H, W).to(dt); w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    b = rnd(3, Cout); temb = rnd(4, B, 256); res = rnd(5, B, H, W, Cout).to(dt)
     conv = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1)
     ref = (conv + temb[:, None, None, 64:64 + Cout]) * 0.5 + res.float()
     out = ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b),
@@ -117,9 +127,10 @@ def test_conv_epilogue_rowvec_residual_scale(ops):
     assert_close(out, ref, what="conv rowvec+res+scale")
 
 
-def test_conv1x1(ops):
+@DTS
+def test_conv1x1(ops, dt):
     B, H, W, Cin, Cout = 2, 8, 8, 320, 320
-    x = rnd(1, B, H, W, Cin).to(bf16); w = rnd(2, Cout, Cin, scale=Cin ** -0.5).to(bf16); b = rnd(3, Cout)
+    x = rnd(1, B, H, W, Cin).to(dt); w = rnd(2, Cout, Cin, scale=Cin ** -0.5).to(dt); b = rnd(3, Cout)
     ref = x.float() @ w.float().t() + b
     out = ops.conv2d_nhwc(dev(x), dev(w), dev(b), taps=1)
     assert_close(out, ref, what="conv1x1")
@@ -128,36 +139,37 @@ def test_conv1x1(ops):
 # ------------------------------------------------------------------------------------------
 # head-split epilogue + attention
 # ------------------------------------------------------------------------------------------
-def to_heads(x, H, DP, scale=1.0):
+def to_heads(x, H, DP, scale=1.0, dt=bf16):
     B, Lt, Cc = x.shape
     d = Cc // H
-    out = torch.zeros(B, H, Lt, DP, dtype=bf16)
-    out[..., :d] = (x.float() * scale).to(bf16).view(B, Lt, H, d).transpose(1, 2)
+    out = torch.zeros(B, H, Lt, DP, dtype=dt)
+    out[..., :d] = (x.float() * scale).to(dt).view(B, Lt, H, d).transpose(1, 2)
     return out
 
 
-def to_heads_t(x, H, DPV, LP):
+def to_heads_t(x, H, DPV, LP, dt=bf16):
     B, Lt, Cc = x.shape
     d = Cc // H
-    out = torch.zeros(B, H, DPV, LP, dtype=bf16)
+    out = torch.zeros(B, H, DPV, LP, dtype=dt)
     out[:, :, :d, :Lt] = x.view(B, Lt, H, d).permute(0, 2, 3, 1)
     return out
 
 
-def test_qkv_head_split(ops):
+@DTS
+def test_qkv_head_split(ops, dt):
     B, Lt, Cc, H = 2, 100, 320, 8
     d = Cc // H
     dpk, dpv = ops.attn_padded_dims(d)
     LP = ops.pad64(Lt)
-    x = rnd(1, B * Lt, Cc).to(bf16); w = rnd(2, 3 * Cc, Cc, scale=Cc ** -0.5).to(bf16)
-    q = torch.zeros(B, H, Lt, dpk, dtype=bf16, device="cuda"); k = torch.zeros_like(q)
-    vt = torch.zeros(B, H, dpv, LP, dtype=bf16, device="cuda")
+    x = rnd(1, B * Lt, Cc).to(dt); w = rnd(2, 3 * Cc, Cc, scale=Cc ** -0.5).to(dt)
+    q = torch.zeros(B, H, Lt, dpk, dtype=dt, device="cuda"); k = torch.zeros_like(q)
+    vt = torch.zeros(B, H, dpv, LP, dtype=dt, device="cuda")
     ops.conv_gemm(dev(x), dev(w), M=B * Lt, N=3 * Cc, Cin=Cc, Hout=Lt, Wout=1, Hin=Lt, Win=1,
                   heads=dict(C=Cc, H=H, D=d, dests=[(q, 0, dpk, Lt, 0.25), (k, 0, dpk, Lt, 1.0), (vt, 1, dpv, LP, 1.0)]))
     y = (x.float() @ w.float().t()).view(B, Lt, 3 * Cc)
-    assert_close(q, to_heads(y[..., :Cc] * 0.25, H, dpk), what="q heads")
-    assert_close(k, to_heads(y[..., Cc:2 * Cc], H, dpk), what="k heads")
-    assert_close(vt, to_heads_t(y[..., 2 * Cc:].to(bf16), H, dpv, LP), what="v^T heads")
+    assert_close(q, to_heads(y[..., :Cc] * 0.25, H, dpk, dt=dt), what="q heads")
+    assert_close(k, to_heads(y[..., Cc:2 * Cc], H, dpk, dt=dt), what="k heads")
+    assert_close(vt, to_heads_t(y[..., 2 * Cc:].to(dt), H, dpv, LP, dt=dt), what="v^T heads")
 
 
 def ref_attn(q, k, v, H):
@@ -168,53 +180,56 @@ def ref_attn(q, k, v, H):
 @pytest.mark.parametrize("D,B,N,L1,L2", [
     (40, 2, 200, 200, 330), (40, 1, 1100, 1100, 0), (80, 2, 144, 144, 100), (160, 1, 64, 64, 80),
     (64, 2, 16, 273, 0), (40, 2, 130, 77, 4), (160, 1, 70, 77, 0)])
-def test_attention(ops, D, B, N, L1, L2):
+@DTS
+def test_attention(ops, D, B, N, L1, L2, dt):
     H = 8
     Cc = H * D
     dpk, dpv = ops.attn_padded_dims(D)
-    q = rnd(1, B, N, Cc).to(bf16)
-    k1 = rnd(2, B, L1, Cc).to(bf16); v1 = rnd(3, B, L1, Cc).to(bf16)
+    q = rnd(1, B, N, Cc).to(dt)
+    k1 = rnd(2, B, L1, Cc).to(dt); v1 = rnd(3, B, L1, Cc).to(dt)
     scale = D ** -0.5 * math.log2(math.e)
-    qh = dev(to_heads(q, H, dpk, scale))
-    out = torch.empty(B, N, Cc, dtype=bf16, device="cuda")
+    qh = dev(to_heads(q, H, dpk, scale, dt=dt))
+    out = torch.empty(B, N, Cc, dtype=dt, device="cuda")
     ref = ref_attn(q, k1, v1, H)
     kw = {}
     if L2:
-        k2 = rnd(4, 1, L2, Cc).to(bf16); v2 = rnd(5, 1, L2, Cc).to(bf16)
+        k2 = rnd(4, 1, L2, Cc).to(dt); v2 = rnd(5, 1, L2, Cc).to(dt)
         s2 = torch.tensor([0.9, 0.0][:B] if B == 2 else [0.9])
         r2 = ref_attn(q, k2.expand(B, -1, -1), v2.expand(B, -1, -1), H)
         # phase 1 is rounded to bf16 before the add (the reference adds two half tensors, :612)
-        ref = ref.to(bf16).float() + s2[:, None, None] * r2
-        kw = dict(k2=dev(to_heads(k2, H, dpk)), v2t=dev(to_heads_t(v2, H, dpv, ops.pad64(L2))), scale2=dev(s2),
+        ref = ref.to(dt).float() + s2[:, None, None] * r2
+        kw = dict(k2=dev(to_heads(k2, H, dpk, dt=dt)), v2t=dev(to_heads_t(v2, H, dpv, ops.pad64(L2), dt=dt)), scale2=dev(s2),
                   L2=L2, L2P=ops.pad64(L2), kv2_bdiv=B)
-    ops.attention(qh, dev(to_heads(k1, H, dpk)), dev(to_heads_t(v1, H, dpv, ops.pad64(L1))), out,
+    ops.attention(qh, dev(to_heads(k1, H, dpk, dt=dt)), dev(to_heads_t(v1, H, dpv, ops.pad64(L1), dt=dt)), out,
                   B=B, H=H, N=N, D=D, L1=L1, L1P=ops.pad64(L1), **kw)
     assert_close(out, ref, atol=1e-2, rtol=1e-2, what=f"attention D={D}")
 
 
-def test_attention_shared_kv_batch_div(ops):
+@DTS
+def test_attention_shared_kv_batch_div(ops, dt):
     """text K/V computed once per prompt and shared by groups of batch rows (kv batch = b // bdiv)."""
     D, H, B, N, L1 = 40, 8, 4, 96, 77
     Cc = H * D
     dpk, dpv = ops.attn_padded_dims(D)
-    q = rnd(1, B, N, Cc).to(bf16); k = rnd(2, 2, L1, Cc).to(bf16); v = rnd(3, 2, L1, Cc).to(bf16)
-    out = torch.empty(B, N, Cc, dtype=bf16, device="cuda")
-    ops.attention(dev(to_heads(q, H, dpk, D ** -0.5 * math.log2(math.e))), dev(to_heads(k, H, dpk)),
-                  dev(to_heads_t(v, H, dpv, 128)), out, B=B, H=H, N=N, D=D, L1=L1, L1P=128, kv1_bdiv=2)
+    q = rnd(1, B, N, Cc).to(dt); k = rnd(2, 2, L1, Cc).to(dt); v = rnd(3, 2, L1, Cc).to(dt)
+    out = torch.empty(B, N, Cc, dtype=dt, device="cuda")
+    ops.attention(dev(to_heads(q, H, dpk, D ** -0.5 * math.log2(math.e), dt=dt)), dev(to_heads(k, H, dpk, dt=dt)),
+                  dev(to_heads_t(v, H, dpv, 128, dt=dt)), out, B=B, H=H, N=N, D=D, L1=L1, L1P=128, kv1_bdiv=2)
     ref = ref_attn(q, k.repeat_interleave(2, 0), v.repeat_interleave(2, 0), H)
     assert_close(out, ref, what="kv batch div")
 
 
-def test_attention_softmax_spike(ops):
+@DTS
+def test_attention_softmax_spike(ops, dt):
     """A key far above the rest late in the sequence forces the online-softmax rescale path."""
     D, H, B, N, L1 = 40, 8, 1, 64, 256
     Cc = H * D
     dpk, dpv = ops.attn_padded_dims(D)
-    q = rnd(1, B, N, Cc).to(bf16); k = rnd(2, B, L1, Cc).to(bf16); v = rnd(3, B, L1, Cc).to(bf16)
+    q = rnd(1, B, N, Cc).to(dt); k = rnd(2, B, L1, Cc).to(dt); v = rnd(3, B, L1, Cc).to(dt)
     k[:, 200] = q[:, 5] * 4.0          # row 5 (and friends) suddenly meet a huge logit in tile 3
-    out = torch.empty(B, N, Cc, dtype=bf16, device="cuda")
-    ops.attention(dev(to_heads(q, H, dpk, D ** -0.5 * math.log2(math.e))), dev(to_heads(k, H, dpk)),
-                  dev(to_heads_t(v, H, dpv, 256)), out, B=B, H=H, N=N, D=D, L1=L1, L1P=256)
+    out = torch.empty(B, N, Cc, dtype=dt, device="cuda")
+    ops.attention(dev(to_heads(q, H, dpk, D ** -0.5 * math.log2(math.e), dt=dt)), dev(to_heads(k, H, dpk, dt=dt)),
+                  dev(to_heads_t(v, H, dpv, 256, dt=dt)), out, B=B, H=H, N=N, D=D, L1=L1, L1P=256)
     assert_close(out, ref_attn(q, k, v, H), atol=2e-2, what="spike")
 
 
@@ -223,8 +238,9 @@ def test_attention_softmax_spike(ops):
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,HW,Cc", [(2, 256, 320), (1, 100, 640), (2, 64, 960), (1, 70, 1280), (1, 16, 1920), (1, 9, 2560)])
 @pytest.mark.parametrize("silu", [False, True])
-def test_groupnorm(ops, B, HW, Cc, silu):
-    x = (rnd(1, B, HW, Cc) * 1.5 + 0.3).to(bf16)
+@DTS
+def test_groupnorm(ops, B, HW, Cc, silu, dt):
+    x = (rnd(1, B, HW, Cc) * 1.5 + 0.3).to(dt)
     g = 1.0 + rnd(2, Cc, scale=0.2); b = rnd(3, Cc, scale=0.2)
     ref = F.group_norm(x.float().transpose(1, 2), 32, g, b, eps=1e-5).transpose(1, 2)
     if silu:
@@ -234,8 +250,9 @@ def test_groupnorm(ops, B, HW, Cc, silu):
 
 
 @pytest.mark.parametrize("rows,Cc", [(300, 320), (77, 768), (10, 1280), (5, 640)])
-def test_layernorm(ops, rows, Cc):
-    x = (rnd(1, rows, Cc) * 2 + 0.5).to(bf16)
+@DTS
+def test_layernorm(ops, rows, Cc, dt):
+    x = (rnd(1, rows, Cc) * 2 + 0.5).to(dt)
     g = 1.0 + rnd(2, Cc, scale=0.2); b = rnd(3, Cc, scale=0.2)
     ref = F.layer_norm(x.float(), (Cc,), g, b, 1e-5)
     assert_close(ops.layer_norm(dev(x), dev(g), dev(b)), ref, atol=2e-2, what="layernorm")
@@ -248,7 +265,8 @@ def test_timestep_embedding(ops):
 
 
 @pytest.mark.parametrize("inpaint", [False, True])
-def test_ddim_cfg_step(ops, inpaint):
+@DTS
+def test_ddim_cfg_step(ops, inpaint, dt):
     from oracle.ddim import DDIMOracle
     B, HW = 3, 500
     sch = DDIMOracle(); sch.set_timesteps(50)
@@ -261,7 +279,7 @@ def test_ddim_cfg_step(ops, inpaint):
         mask = (rnd(3, B, HW) > 0).float(); zi = rnd(4, B, HW, 4); nz = rnd(5, B, HW, 4)
         ref = (1 - mask[..., None]) * sch.add_noise(zi, nz, t_next) + mask[..., None] * ref
         kw = dict(mask=dev(mask), z_img=dev(zi), noise=dev(nz), a_next=float(sch.alphas_cumprod[t_next]))
-    zd = dev(z.clone()); xn = torch.empty(2 * B, HW, 8, dtype=bf16, device="cuda")
+    zd = dev(z.clone()); xn = torch.empty(2 * B, HW, 8, dtype=dt, device="cuda")
     prev_t = t - 1000 // 50
     ops.ddim_cfg_step(zd, dev(eps), xn, guidance=g, a_t=float(sch.alphas_cumprod[t]),
                       a_prev=float(sch.alphas_cumprod[prev_t]), **kw)
@@ -271,13 +289,14 @@ def test_ddim_cfg_step(ops, inpaint):
     assert float(xn[..., 4:].abs().max()) == 0.0
 
 
-def test_add_concat_cast(ops):
-    a = rnd(1, 2, 50, 320).to(bf16); b = rnd(2, 2, 50, 640).to(bf16); c = rnd(3, 2, 50, 640).to(bf16)
+@DTS
+def test_add_concat_cast(ops, dt):
+    a = rnd(1, 2, 50, 320).to(dt); b = rnd(2, 2, 50, 640).to(dt); c = rnd(3, 2, 50, 640).to(dt)
     assert_close(ops.add(dev(b), dev(c), 0.5), b.float() + 0.5 * c.float(), what="add")
     assert_close(ops.concat_channels(dev(a), dev(b)), torch.cat([a, b], -1), atol=0, rtol=0, what="concat")
     assert_close(ops.concat_channels(dev(a), dev(b), dev(c)), torch.cat([a.float(), b.float() + c.float()], -1), what="concat+add")
     f = rnd(4, 1000)
-    assert_close(ops.f32_to_bf16(dev(f)), f.to(bf16), atol=0, rtol=0, what="cast")
+    assert_close(ops.f32_to_16(dev(f), dt), f.to(dt), atol=0, rtol=0, what="cast")
 
 
 def test_no_cpu_fallback(ops):
