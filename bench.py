@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py -- 512x512 / 50-step images per second of the IMAGDressing-v1 denoising hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch: the garment UNet once + 50 DDIM steps of the
+CFG-batched denoising UNet (hybrid attention with the garment branch on the cond rows) for
+``--batch`` images per GPU sharing one garment (BASELINE.json configs[1]: SD1.5 bf16, 512x512,
+50 steps, batch 4 on one MI355X, garment cross-attn only).  Inputs (text / garment-token
+embeddings, garment latent, initial latents) are synthetic, seeded, and resident in HBM before the
+timed region; weights are random-init of the SD1.5 architecture (no checkpoints exist offline).
+At N > 1 every rank runs its own shard of the images (weak scaling: per-GPU batch fixed) and the
+garment features are computed on rank 0 and broadcast (RCCL) once per step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16/fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU sharing one garment")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=1)
+    return ap.parse_args()
+
+
+def build_pipeline(device, dtype, rank):
+    from imagdressing_amd import unet as E
+    from imagdressing_amd.adapter import attention_processor as AP
+    from imagdressing_amd.adapter.resampler import Resampler
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+    from imagdressing_amd.scheduler import DDIMScheduler
+    unet = E.UNet2DConditionModel.random_init(seed=0, device=device, dtype=dtype)
+    ref_unet = E.UNet2DConditionModel.random_init(seed=1, device=device, dtype=dtype)
+    boc = unet.cfg["block_out_channels"]
+    procs = {}
+    g = torch.Generator(device="cpu").manual_seed(2)
+    for name in unet.attn_processors.keys():
+        if name.startswith("mid_block"):
+            hs = boc[-1]
+        elif name.startswith("up_blocks"):
+            hs = list(reversed(boc))[int(name[len("up_blocks.")])]
+        else:
+            hs = boc[int(name[len("down_blocks.")])]
+        if name.endswith("attn1.processor"):
+            p = AP.RefSAttnProcessor2_0(name, hs)                  # inference_IMAGdressing.py:80
+            with torch.no_grad():                                  # fan-in scaled synthetic weights
+                p.to_k_ref.weight.copy_(torch.randn(hs, hs, generator=g) * hs ** -0.5)
+                p.to_v_ref.weight.copy_(torch.randn(hs, hs, generator=g) * hs ** -0.5)
+        else:
+            p = AP.CAttnProcessor2_0(name, hidden_size=hs, cross_attention_dim=768)   # :82
+        procs[name] = p
+    unet.set_attn_processor(procs)
+    ref_unet.set_attn_processor({n: AP.CacheAttnProcessor2_0() for n in ref_unet.attn_processors.keys()})   # :93-94
+    torch.manual_seed(3)
+    proj = Resampler(dim=768, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=768, ff_mult=4)   # :55-64
+    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                        clip_sample=False, set_alpha_to_one=False, steps_offset=1)          # :119-127
+    pipe = IMAGDressing_v1(vae=None, reference_unet=ref_unet, unet=unet, tokenizer=None, text_encoder=None, image_encoder=None,
+                           ImgProj=proj, scheduler=sch, safety_checker=None, feature_extractor=None)
+    return pipe
+
+
+def synthetic_inputs(args, device, dtype, rank, world):
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    lat_hw = args.res // 8
+    n_total = args.batch * world
+    inp = dict(
+        prompt_embeds=(torch.randn(1, 77, 768, generator=gen) * 0.5).to(device),
+        negative_prompt_embeds=(torch.randn(1, 77, 768, generator=gen) * 0.5).to(device),
+        ref_clip_hidden_states=(torch.randn(1, 257, 1280, generator=gen) * 0.5).to(device=device, dtype=dtype),
+        ref_image_latents=(torch.randn(1, 4, lat_hw, lat_hw, generator=gen)).to(device),
+        # per-image seeds 42, 43, ... drawn on the CPU (identical on every vendor); rank r owns its block
+        latents=torch.stack([torch.randn(4, lat_hw, lat_hw, generator=torch.Generator().manual_seed(42 + i))
+                             for i in range(n_total)]).to(device),
+    )
+    return inp
+
+
+def attn_flops_hybrid_level0(batch, N, M, C):
+    """Algorithmic FLOPs of ONE launch of the fused attention kernel at UNet level 0 in the CFG batch:
+    `batch` cond rows run self + garment attention (4 N^2 C + 4 N M C), `batch` uncond rows run self only
+    (projections are separate GEMM launches and are not counted here)."""
+    return batch * (4.0 * N * N * C + 4.0 * N * M * C) + batch * (4.0 * N * N * C)
+
+
+def cpu_baseline(args):
+    """Reference-semantics CPU port (oracle/: reference processors' math + restated diffusers UNet, fp32
+    torch) timed on this host: `cpu-baseline-steps` DDIM steps at batch 1 = 2 B=1 UNet forwards each
+    (IMAGDressing_v1_pipeline.py:499-518), extrapolated linearly to 50 steps (the one-off garment pass is
+    < 2 % of a run and is left out of the sample, which makes the CPU number slightly optimistic)."""
+    from imagdressing_amd import unet as E
+    from oracle import processors as OP
+    from oracle import sd15
+    from oracle.ddim import DDIMOracle
+    torch.manual_seed(0)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))     # more torch threads than ~16 only adds contention at batch 1
+    torch.set_num_threads(cores)
+    lat = args.res // 8
+    with torch.no_grad():
+        u = sd15.UNet2DConditionModel()       # default-initialised fp32 weights (values do not affect timing)
+        names = list(u.attn_processors.keys())
+        boc = sd15.SD15["block_out_channels"]
+        procs, sa = {}, {}
+        lvl_tokens = {0: lat * lat, 1: (lat // 2) ** 2, 2: (lat // 4) ** 2, 3: (lat // 8) ** 2}
+        for n in names:
+            if n.startswith("mid_block"):
+                hs, lv = boc[-1], 3
+            elif n.startswith("up_blocks"):
+                i = int(n[len("up_blocks.")]); hs, lv = list(reversed(boc))[i], 3 - i
+            else:
+                i = int(n[len("down_blocks.")]); hs, lv = boc[i], i
+            if n.endswith("attn1.processor"):
+                procs[n] = OP.RefSAttn(n, hs)
+                sa[n] = torch.randn(1, lvl_tokens[lv], hs)
+            else:
+                procs[n] = OP.CAttn(n, hs, 768)
+        u.set_attn_processor(procs)
+        sch = DDIMOracle(); ts = sch.set_timesteps(args.ddim_steps)
+        z = torch.randn(1, 4, lat, lat); pe = torch.randn(1, 77, 768) * 0.5; ne = torch.randn(1, 77, 768) * 0.5
+        per_step, note = [], ""
+        for i in range(args.cpu_baseline_steps):
+            t = ts[i]
+            t0 = time.time()
+            ec = u(z, t, pe, cross_attention_kwargs={"sa_hidden_states": sa})      # cond pass, garment branch on
+            t_c = time.time() - t0
+            if t_c > 60.0:      # keep the default bench run bounded on slow hosts
+                per_step.append(t_c * (1.0 + 0.8))
+                note = "; uncond pass not run (cond pass > 60 s), estimated as 0.8 x cond"
+                break
+            t0 = time.time()
+            eu = u(z, t, ne)                                                         # uncond pass
+            t_u = time.time() - t0
+            z = sch.step(eu + 7.5 * (ec - eu), t, z)
+            per_step.append(t_c + t_u)
+        dt = sum(per_step) / len(per_step)
+    return dict(value=1.0 / (dt * args.ddim_steps), unit="images/s", cores=cores, kind="port",
+                sample=f"{len(per_step)} of {args.ddim_steps} DDIM steps at batch 1 (reference loop semantics: cond + uncond fp32 UNet "
+                       f"forward per step, {dt:.2f} s/step, torch {torch.__version__} on {cores} threads), extrapolated x{args.ddim_steps}{note}")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)     # "nccl" == RCCL on ROCm
+
+    from imagdressing_amd import dist as imd_dist
+    from imagdressing_amd import ops
+    pipe = build_pipeline(device, dtype, rank)
+    inp = synthetic_inputs(args, device, dtype, rank, world)
+    lat_hw = args.res // 8
+    N0 = lat_hw * lat_hw
+
+    def one_step():
+        return pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=args.res, height=args.res,
+                    num_inference_steps=args.ddim_steps, guidance_scale=7.5, num_images_per_prompt=args.batch * world,
+                    image_scale=1.0, output_type="latent", shard_over_ranks=world > 1, **inp).images
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    # roofline hook: bracket every level-0 hybrid-attention launch of the timed region with HIP events
+    hook = {"match": lambda B, H, N, D, L1, L2: D == 40 and N == N0 and L2 == N0, "events": []}
+    ops.ATTN_EVENT_HOOK = hook
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.ATTN_EVENT_HOOK = None
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(out).all().item())
+
+    if rank == 0:
+        images = args.batch * world * args.steps
+        ms = [a.elapsed_time(b) for a, b in hook["events"]]
+        roof = None
+        if ms:
+            avg_s = sum(ms) / len(ms) * 1e-3
+            fl = attn_flops_hybrid_level0(args.batch, N0, N0, 320)
+            ach = fl / avg_s / 1e12
+            roof = dict(bound="mfma", kernel="attn_kernel<D=40> (fused hybrid attention, UNet level 0, CFG batch)",
+                        achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
+                        traffic=None, launches=len(ms), avg_launch_ms=round(avg_s * 1e3, 4), flops_per_launch=fl)
+        line = {
+            "metric": "512x512 50-step images/sec (whole node)", "value": round(images / elapsed, 4), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: SD1.5 {args.dtype}, {args.res}x{args.res}, {args.ddim_steps} DDIM steps, "
+                                   f"batch {args.batch}/GPU sharing one garment, garment cross-attn only (RefS + CAttn processors), "
+                                   "random-init weights",
+                       "images_per_gpu": args.batch, "global_batch": args.batch * world, "guidance_scale": 7.5,
+                       "parallelism": f"dp{world} (image shards; garment features broadcast once per batch)"},
+            "outputs_finite": finite,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
