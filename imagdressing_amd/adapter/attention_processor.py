@@ -438,11 +438,11 @@ class IPAttnProcessor2_0(_IPBase):
 
 # ---- legacy names: defined by the reference but used by none of its entry points ----------------
 class BaseSAttnProcessor2_0(nn.Module, _FusedBase):
-    """Plain self-attention with a name (attention_processor.py:298-389)."""
+    """Plain attention with a name (attention_processor.py:298-389)."""
 
-    def __init__(self, name, hidden_size, cross_attention_dim=None):
+    def __init__(self, name, cross_attention_dim=None):
         super().__init__()
-        self.name, self.hidden_size, self.cross_attention_dim = name, hidden_size, cross_attention_dim
+        self.name, self.cross_attention_dim = name, cross_attention_dim
         self._plain = AttnProcessor2_0()
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
@@ -450,17 +450,39 @@ class BaseSAttnProcessor2_0(nn.Module, _FusedBase):
         return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
 
 
-class SAttnProcessor2_0(BaseSAttnProcessor2_0):
+class SAttnProcessor2_0(nn.Module, _FusedBase):
     """Concat-KV variant (attention_processor.py:103-199, ONE softmax over [self; garment] keys, :157-159).
     Unused by every reference entry point; kept importable, executes plain self-attention when no
     garment tokens are passed and refuses the concat form (different arithmetic from the hybrid)."""
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, sa_hidden_states=None, **kwargs):
+    def __init__(self, name, hidden_size, cross_attention_dim=None):
+        super().__init__()
+        self.name, self.hidden_size, self.cross_attention_dim = name, hidden_size, cross_attention_dim
+        self._plain = AttnProcessor2_0()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 sa_hidden_states=None, imd_residual=None, **kwargs):
         if sa_hidden_states is not None:
             raise NotImplementedError("SAttnProcessor2_0 (single softmax over concatenated keys) is legacy and unused; "
                                       "use RefSAttnProcessor2_0")
-        return super().__call__(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, **kwargs)
+        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
 
 
-class RefCAttnProcessor2_0(CAttnProcessor2_0):
-    """Legacy name (attention_processor.py:630-743); unused by the reference's entry points."""
+class RefCAttnProcessor2_0(nn.Module, _FusedBase):
+    """Legacy cross-attention + garment-token variant (attention_processor.py:630-743); unused by the reference's
+    entry points.  Parameters are kept for checkpoint compatibility; it executes as text cross-attention and
+    refuses the garment form."""
+
+    def __init__(self, name, hidden_size, cross_attention_dim=None, scale=1.0):
+        super().__init__()
+        self.name, self.hidden_size, self.cross_attention_dim = name, hidden_size, cross_attention_dim
+        self.to_k_ref = nn.Linear(hidden_size, hidden_size, bias=False)
+        self.to_v_ref = nn.Linear(hidden_size, hidden_size, bias=False)
+        self.scale = scale
+        self._plain = AttnProcessor2_0()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 cond_hidden_states=None, sa_hidden_states=None, imd_residual=None, **kwargs):
+        if cond_hidden_states is not None:
+            raise NotImplementedError("RefCAttnProcessor2_0's garment form is legacy and unused; use RefSAttnProcessor2_0 on attn1")
+        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)

@@ -237,6 +237,32 @@ class PipelineBase:
         return self.garment_features(ref_latents, cloth_tokens)
 
 
+def controlnet_keep(num_steps: int, start: float, end: float) -> List[float]:
+    """diffusers' per-step ControlNet gate (..._pipeline_ipa_controlnet.py:582-590)."""
+    return [1.0 - float(i / num_steps < start or (i + 1) / num_steps > end) for i in range(num_steps)]
+
+
+def first(x):
+    return x[0] if isinstance(x, (list, tuple)) else x
+
+
+def to_image_tensor(image, device, normalize: bool) -> torch.Tensor:
+    """PIL / ndarray / tensor -> [B, 3, H, W] float in [0, 1] (or [-1, 1] when ``normalize``)."""
+    import numpy as np
+    if isinstance(image, torch.Tensor):
+        t = image.float()
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+    else:
+        if not isinstance(image, (list, tuple)):
+            image = [image]
+        arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.float32) / 255.0 for im in image]
+        t = torch.from_numpy(np.stack(arrs)).permute(0, 3, 1, 2)
+        if normalize:
+            t = t * 2.0 - 1.0
+    return t.to(device)
+
+
 def set_scale_by_type(unet, cls, **attrs):
     for proc in unet.attn_processors.values():
         if isinstance(proc, cls):
@@ -244,5 +270,5 @@ def set_scale_by_type(unet, cls, **attrs):
                 setattr(proc, k, v)
 
 
-__all__ = ["PipelineBase", "StableDiffusionPipelineOutput", "randn_tensor", "set_scale_by_type",
+__all__ = ["controlnet_keep", "first", "to_image_tensor", "PipelineBase", "StableDiffusionPipelineOutput", "randn_tensor", "set_scale_by_type",
            "RefSAttnProcessor2_0", "LoraRefSAttnProcessor2_0", "LoRAIPAttnProcessor2_0", "IPAttnProcessor2_0"]

@@ -50,6 +50,8 @@ _checked_devices = set()
 
 
 def ensure_device(device: torch.device):
+    if device.type != "cuda":
+        raise L.ImdError(f"tensor is on {device}; imagdressing_amd runs on MI355X (gfx950) only -- there is no CPU path")
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _checked_devices:
         L.check(L.load().imd_device_check(idx))

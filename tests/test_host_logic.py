@@ -1,0 +1,174 @@
+"""Host-side logic that needs no GPU: schedule, parameter inventory, plugin surface, sharding."""
+import os
+
+import pytest
+import torch
+
+from imagdressing_amd import dist as D
+from imagdressing_amd import unet as E
+from imagdressing_amd.scheduler import DDIMScheduler
+from oracle import sd15
+from oracle.ddim import DDIMOracle
+
+
+def make_sched():
+    return DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                         clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+
+
+@pytest.mark.parametrize("n", [20, 50])
+def test_ddim_schedule_matches_oracle_and_known_values(n):
+    s, o = make_sched(), DDIMOracle()
+    s.set_timesteps(n); ts = o.set_timesteps(n)
+    assert s.timesteps.tolist() == ts.tolist()
+    # leading spacing with steps_offset=1: t_i = (1000/n)(n-1-i) + 1
+    assert ts.tolist() == [(1000 // n) * (n - 1 - i) + 1 for i in range(n)]
+    assert ts[0] == 1000 - 1000 // n + 1 and ts[-1] == 1
+    for t in ts.tolist():
+        assert s.alpha(t) == pytest.approx(float(o.alphas_cumprod[t]), rel=0, abs=0)
+        prev = t - 1000 // n
+        exp = float(o.alphas_cumprod[prev]) if prev >= 0 else float(o.alphas_cumprod[0])   # set_alpha_to_one=False
+        assert s.alpha_prev(t) == exp
+    # published SD schedule end points: alphas_cumprod[0] = 1 - 0.00085, [999] ~ 0.00466
+    assert float(o.alphas_cumprod[0]) == pytest.approx(1 - 0.00085, abs=1e-7)
+    assert float(o.alphas_cumprod[999]) == pytest.approx(0.004660, abs=2e-5)
+
+
+def test_unet_and_controlnet_inventories_match_oracle_modules():
+    u = sd15.UNet2DConditionModel().state_dict()
+    s = E.unet_param_shapes()
+    assert set(u) == set(s) and all(tuple(u[k].shape) == s[k] for k in s)
+    assert sum(v.numel() for v in u.values()) == 859_520_964          # SD1.5 UNet parameter count
+    c = sd15.ControlNetModel().state_dict()
+    cs = E.controlnet_param_shapes()
+    assert set(c) == set(cs) and all(tuple(c[k].shape) == cs[k] for k in cs)
+    assert sum(v.numel() for v in c.values()) == 361_279_120          # SD1.5 ControlNet parameter count
+
+
+def test_processor_names_and_order():
+    names = list(sd15.UNet2DConditionModel().attn_processors.keys())
+    assert len(names) == 32
+    assert names[0] == "down_blocks.0.attentions.0.transformer_blocks.0.attn1.processor"
+    assert names[12].startswith("up_blocks.1.") and names[-1] == "mid_block.attentions.0.transformer_blocks.0.attn2.processor"
+    assert [i for i, n in enumerate(names) if n.endswith("attn1.processor")] == list(range(0, 32, 2))   # adapter_modules.{even}
+
+
+REF = "/root/reference/adapter/attention_processor.py"
+
+
+@pytest.mark.skipif(not os.path.isfile(REF), reason="reference checkout not present")
+def test_plugin_surface_matches_reference():
+    """same class names, ctor signatures, state_dict keys and isinstance relations as the reference module"""
+    import inspect
+    from imagdressing_amd.adapter import attention_processor as A
+    from imagdressing_amd.adapter import resampler as R
+    from oracle.ref_loader import load_reference_adapter
+    ap, rs = load_reference_adapter()
+    ctor = {
+        "RefSAttnProcessor2_0": ("n", 64), "LoraRefSAttnProcessor2_0": ("n", 64), "RefLoraSAttnProcessor2_0": ("n", 64),
+        "CAttnProcessor2_0": ("n", 64, 96), "LoRAIPAttnProcessor2_0": (64, 96), "IPAttnProcessor2_0": (64, 96),
+        "SAttnProcessor2_0": ("n", 64), "BaseSAttnProcessor2_0": ("n", 64), "RefCAttnProcessor2_0": ("n", 64, 96),
+    }
+    for cls, args in ctor.items():
+        ours, theirs = getattr(A, cls), getattr(ap, cls)
+        assert list(inspect.signature(ours.__init__).parameters) == list(inspect.signature(theirs.__init__).parameters), cls
+        so, st = ours(*args).state_dict(), theirs(*args).state_dict()
+        assert {k: tuple(v.shape) for k, v in so.items()} == {k: tuple(v.shape) for k, v in st.items()}, cls
+    assert list(inspect.signature(A.CacheAttnProcessor2_0.__init__).parameters) == ["self"]
+    # sibling relations the reference pipelines' isinstance checks rely on
+    assert not isinstance(A.RefLoraSAttnProcessor2_0("n", 64), A.LoraRefSAttnProcessor2_0)
+    assert not isinstance(A.LoraRefSAttnProcessor2_0("n", 64), A.RefSAttnProcessor2_0)
+    assert not isinstance(A.IPAttnProcessor2_0(64, 96), A.LoRAIPAttnProcessor2_0)
+    cfg = dict(dim=64, depth=2, dim_head=16, heads=4, num_queries=4, embedding_dim=48, output_dim=32, ff_mult=4)
+    assert list(inspect.signature(R.Resampler.__init__).parameters) == list(inspect.signature(rs.Resampler.__init__).parameters)
+    a, b = R.Resampler(**cfg).state_dict(), rs.Resampler(**cfg).state_dict()
+    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+    a, b = R.ProjPlusModel().state_dict(), rs.ProjPlusModel().state_dict()
+    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+    assert list(inspect.signature(R.ProjPlusModel.forward).parameters) == list(inspect.signature(rs.ProjPlusModel.forward).parameters)
+
+
+@pytest.mark.skipif(not os.path.isfile(REF), reason="reference checkout not present")
+def test_pipeline_call_signatures_cover_reference():
+    """every keyword the reference's __call__ / __init__ accept is accepted here (extensions are appended)"""
+    import ast
+    import inspect
+    import importlib
+    for mod in ("IMAGDressing_v1_pipeline", "IMAGDressing_v1_pipeline_controlnet", "IMAGDressing_v1_pipeline_ipa_controlnet",
+                "IMAGDressing_v1_pipeline_controlnet_inpainting"):
+        tree = ast.parse(open(f"/root/reference/dressing_sd/pipelines/{mod}.py").read())
+        cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "IMAGDressing_v1"][0]
+        ref = {f.name: [a.arg for a in f.args.args] for f in cls.body if isinstance(f, ast.FunctionDef)}
+        ours = importlib.import_module(f"dressing_sd.pipelines.{mod}").IMAGDressing_v1
+        for fn in ("__init__", "__call__"):
+            mine = list(inspect.signature(getattr(ours, fn)).parameters)
+            assert mine[:len(ref[fn])] == ref[fn], (mod, fn, mine, ref[fn])
+        for meth in ("set_scale",) + (("set_ipa_scale", "get_image_embeds", "init_proj", "load_ip_adapter") if "ipa" in mod else ()):
+            assert hasattr(ours, meth), (mod, meth)
+
+
+def test_set_scale_semantics():
+    from imagdressing_amd.adapter import attention_processor as A
+    from imagdressing_amd.dressing_sd.pipelines._base import set_scale_by_type
+
+    class U:
+        attn_processors = {"a": A.RefSAttnProcessor2_0("a", 64), "b": A.LoraRefSAttnProcessor2_0("b", 64),
+                           "c": A.RefLoraSAttnProcessor2_0("c", 64), "d": A.CAttnProcessor2_0("d", 64, 96)}
+    set_scale_by_type(U, A.RefSAttnProcessor2_0, scale=0.3)
+    assert U.attn_processors["a"].scale == 0.3 and U.attn_processors["b"].scale == 1.0
+    set_scale_by_type(U, A.LoraRefSAttnProcessor2_0, scale=0.7, lora_scale=0.2)
+    assert (U.attn_processors["b"].scale, U.attn_processors["b"].lora_scale) == (0.7, 0.2)
+    assert U.attn_processors["c"].scale == 1.0            # app.py's class is NOT matched, as in the reference
+
+
+def test_tensor_cache_tracks_identity_and_version():
+    from imagdressing_amd.adapter.attention_processor import _TensorCache
+    c = _TensorCache(2)
+    a = torch.zeros(4)
+    assert c.get((a,)) is None
+    c.put((a,), "v1")
+    assert c.get((a,)) == "v1"
+    a.add_(1)                                   # in-place change bumps the version -> stale entry is not returned
+    assert c.get((a,)) is None
+    b = torch.zeros(4)
+    c.put((b,), "vb"); c.put((a,), "va")
+    assert c.get((b,)) == "vb" and c.get((a,)) == "va"
+    c.put((torch.ones(1),), "x")               # capacity 2: the least recently used entry is dropped
+    assert sum(c.get((t,)) is not None for t in (a, b)) == 1
+
+
+def test_shard_bounds_partition():
+    for n in (1, 4, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [D.shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_feature_layout_matches_oracle_garment_features():
+    from oracle import processors as OP
+    from oracle.pipeline import garment_features
+    from tests.harness import SMALL, oracle_cfg
+    o = sd15.UNet2DConditionModel(oracle_cfg(SMALL))
+    o.set_attn_processor({n: OP.CacheAttn() for n in o.attn_processors})
+    with torch.no_grad():
+        feats = garment_features(o, torch.randn(1, 4, 16, 24), torch.randn(2, 16, 64))
+
+    class U:
+        cfg = dict(E.SD15_CONFIG, **SMALL)
+        attn_processors = feats
+    layout = D.feature_layout(U, (16, 24))
+    assert [(n, tuple(feats[n].shape)) for n in feats] == layout
+    names = [n for n, _ in layout if n.endswith("attn1.processor")]
+    flat, lay = D.pack_features(feats, names)
+    back = D.unpack_features(flat, lay)
+    assert all(torch.equal(back[n], feats[n]) for n in names)
+
+
+def test_controlnet_keep():
+    from imagdressing_amd.dressing_sd.pipelines._base import controlnet_keep
+    assert controlnet_keep(4, 0.0, 1.0) == [1.0] * 4
+    assert controlnet_keep(4, 0.5, 1.0) == [0.0, 0.0, 1.0, 1.0]
+    assert controlnet_keep(4, 0.0, 0.5) == [1.0, 1.0, 0.0, 0.0]
