@@ -183,7 +183,9 @@ class AttnProcessor2_0(_FusedBase):
     """Plain attention (diffusers' default processor; what a ControlNet / un-patched UNet runs)."""
 
     def __init__(self):
-        self._text = _TensorCache()
+        # ONE instance may serve every attention layer of a model (``set_attn_processor(proc)``, as diffusers
+        # does): cached K/V are keyed by the conditioning tensor AND the layer's own projection weights.
+        self._text = _TensorCache(capacity=256)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  imd_residual=None, **kwargs):
@@ -193,10 +195,11 @@ class AttnProcessor2_0(_FusedBase):
             out = _fused_attention(x, attn.heads, wq_or_qkv=attn.packed("qkv"), self_attn=True, wo=wo, bo=bo,
                                    residual=imd_residual)
         else:
-            kv = self._text.get((encoder_hidden_states,))
+            srcs = (encoder_hidden_states, attn.to_k.weight, attn.to_v.weight)
+            kv = self._text.get(srcs)
             if kv is None:
                 e = encoder_hidden_states.to(device=x.device, dtype=x.dtype).contiguous()
-                kv = self._text.put((encoder_hidden_states,), _project_kv(e, attn.packed("kv"), attn.heads))
+                kv = self._text.put(srcs, _project_kv(e, attn.packed("kv"), attn.heads))
             out = _fused_attention(x, attn.heads, wq_or_qkv=attn.to_q.weight, self_attn=False, kv1=kv,
                                    kv1_bdiv=self._ehs_bdiv(x.shape[0], encoder_hidden_states), wo=wo, bo=bo,
                                    residual=imd_residual)
@@ -389,7 +392,8 @@ class _IPBase(nn.Module, _FusedBase, _LoraFold):
         wq, wkv, wo = self._weights(attn)
         wsrc = (self.to_k_ip.weight, self.to_v_ip.weight)
         ls = float(getattr(self, "lora_scale", 0.0))
-        kvs = self._kv.get((encoder_hidden_states,) + wsrc, extra=(ls, x.dtype))
+        ksrc = (encoder_hidden_states, attn.to_k.weight, attn.to_v.weight) + wsrc
+        kvs = self._kv.get(ksrc, extra=(ls, x.dtype))
         if kvs is None:
             wip = self._wip.get(wsrc, extra=(x.dtype,))
             if wip is None:
@@ -397,7 +401,7 @@ class _IPBase(nn.Module, _FusedBase, _LoraFold):
                                     extra=(x.dtype,))
             e = encoder_hidden_states.to(device=x.device, dtype=x.dtype)
             end = e.shape[1] - self.num_tokens                                       # :811
-            kvs = self._kv.put((encoder_hidden_states,) + wsrc,
+            kvs = self._kv.put(ksrc,
                                (_project_kv(e[:, :end].contiguous(), wkv, attn.heads),
                                 _project_kv(e[:, end:].contiguous(), wip, attn.heads)), extra=(ls, x.dtype))
         B = x.shape[0]

@@ -51,15 +51,38 @@ def build_pair(cfg=None, seed=0, device="cuda", kind="refs", ref_seed=7, with_co
     assert names == list(o_u.attn_processors.keys()), "processor name order differs between oracle and engine"
     rw = ref_weights([n for n in names if n.endswith("attn1.processor")], boc, ref_seed)
     o_procs, e_procs = {}, {}
+    g = torch.Generator().manual_seed(ref_seed + 100)
+    cd = full["cross_attention_dim"]
+
+    def fill_lora(op, ep, c, kd, rank):
+        with torch.no_grad():
+            for nm, cin in (("q", c), ("k", kd), ("v", kd), ("out", c)):
+                down = torch.randn(rank, cin, generator=g) * cin ** -0.5
+                up = torch.randn(c, rank, generator=g) * rank ** -0.5
+                for p in (op, ep):
+                    layer = getattr(p, f"to_{nm}_lora")
+                    layer.down.weight.copy_(down); layer.up.weight.copy_(up)
     for n in names:
         c = hidden_size_of(n, boc)
         if n.endswith("attn1.processor"):
-            op, ep = OP.RefSAttn(n, c), AP.RefSAttnProcessor2_0(n, c)
+            if kind == "ipa":
+                op, ep = OP.LoraRefSAttn(n, c, rank=16, lora_scale=0.2), AP.LoraRefSAttnProcessor2_0(n, c, rank=16, lora_scale=0.2)
+                fill_lora(op, ep, c, c, 16)
+            else:
+                op, ep = OP.RefSAttn(n, c), AP.RefSAttnProcessor2_0(n, c)
             with torch.no_grad():
                 for p in (op, ep):
                     p.to_k_ref.weight.copy_(rw[n]["k"]); p.to_v_ref.weight.copy_(rw[n]["v"])
+        elif kind == "ipa":
+            op = OP.LoRAIPAttn(c, cd, rank=16, lora_scale=0.2, scale=0.9, num_tokens=4)
+            ep = AP.LoRAIPAttnProcessor2_0(c, cd, rank=16, lora_scale=0.2, scale=0.9, num_tokens=4)
+            fill_lora(op, ep, c, cd, 16)
+            kip, vip = torch.randn(c, cd, generator=g) * cd ** -0.5, torch.randn(c, cd, generator=g) * cd ** -0.5
+            with torch.no_grad():
+                for p in (op, ep):
+                    p.to_k_ip.weight.copy_(kip); p.to_v_ip.weight.copy_(vip)
         else:
-            op, ep = OP.CAttn(n, c, full["cross_attention_dim"]), AP.CAttnProcessor2_0(n, c, full["cross_attention_dim"])
+            op, ep = OP.CAttn(n, c, cd), AP.CAttnProcessor2_0(n, c, cd)
         o_procs[n], e_procs[n] = op, ep
     o_u.set_attn_processor(o_procs); e_u.set_attn_processor(e_procs)
     o_r.set_attn_processor({n: OP.CacheAttn() for n in names})

@@ -110,3 +110,94 @@ def test_pipeline_small_20_steps(small_pair):
     scale = st["ref_std"]
     bar = dict(max_abs=1e-2, rel_rms=4e-3) if p["dtype"] == torch.float16 else dict(max_abs=8e-2, rel_rms=2.5e-2)
     assert st["max_abs"] < bar["max_abs"] * scale and st["rel_rms"] < bar["rel_rms"], st
+
+
+def _sched():
+    from imagdressing_amd.scheduler import DDIMScheduler
+    return DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                         clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+
+
+def _traj_bar(dtype):
+    """Bars for multi-step latent trajectories, RELATIVE to the oracle's final latent scale (seeded random weights
+    are not a trained denoiser: the latent grows ~6-17x, so an absolute 1e-2 is meaningless there).  fp16: rms error
+    < 0.4 % and worst element < 2 % of the latent std (1e-2 x std is met on the plain / IPA paths; the inpaint blend
+    concentrates the error in the masked region whose own std is ~2x the global one).  bf16: 2.5 % / 15 %."""
+    return dict(max_abs=2e-2, rel_rms=4e-3) if dtype == torch.float16 else dict(max_abs=0.15, rel_rms=2.5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_pipeline_ipa_controlnet_small(dtype):
+    """config-3 path: LoraRefS + LoRAIP processors (LoRA folded into weights), 4 face tokens appended to the text
+    tokens, pose ControlNet residuals (cond / uncond halves) -- vs the oracle's reference-loop semantics."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline_ipa_controlnet import IMAGDressing_v1
+    from oracle.ddim import DDIMOracle
+    from oracle.pipeline import denoise
+    p = build_pair(SMALL, seed=3, kind="ipa", with_controlnet=True, dtype=dtype)
+    steps, gs = 8, 7.0
+    lat = g(42, 1, 4, 16, 16)
+    pe, ne = g(10, 1, 77, 64, scale=0.5), g(11, 1, 77, 64, scale=0.5)
+    face_p, face_n = g(14, 1, 4, 64, scale=0.5), g(15, 1, 4, 64, scale=0.5)
+    cloth = g(12, 2, 16, 64, scale=0.5); refl = g(13, 1, 4, 16, 16)
+    pose = torch.rand(1, 3, 128, 128, generator=torch.Generator().manual_seed(16))
+    # oracle: prompt embeds with face tokens appended (:555-557); ControlNet gets text-only [neg, pos] (:550)
+    ref = denoise(p["o_unet"], p["o_ref"], DDIMOracle(), lat, torch.cat([pe, face_p], 1), torch.cat([ne, face_n], 1), cloth, refl,
+                  steps, gs, controlnet=p["o_ctrl"], control_image=pose, prompt_embeds_control=torch.cat([ne, pe]),
+                  conditioning_scale=0.8)
+
+    class FaceProj:      # image_proj_model stand-in returning the given face tokens
+        def __call__(self, idv, clip):
+            return (face_p if float(idv.abs().sum()) > 0 else face_n).cuda()
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           controlnet=p["e_ctrl"], image_encoder=None, ImgProj=lambda h: h, ip_ckpt=None, scheduler=_sched())
+    pipe.image_proj_model = FaceProj()
+    out = pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=128, height=128,
+               num_inference_steps=steps, guidance_scale=gs, pose_image=pose.cuda(), faceid_embeds=torch.ones(1, 512),
+               face_clip_hidden_states=torch.zeros(1, 257, 1280), face_uncond_clip_hidden_states=torch.zeros(1, 257, 1280),
+               image_scale=1.0, ipa_scale=0.9, s_lora_scale=0.2, c_lora_scale=0.2, controlnet_conditioning_scale=0.8,
+               prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(),
+               ref_image_latents=refl.cuda(), latents=lat.cuda(), output_type="latent").images
+    st = err_stats(out, ref); record(f"pipeline_ipa_controlnet_small[{dtype}]", st)
+    bar = _traj_bar(dtype)
+    assert torch.isfinite(out).all()
+    assert st["max_abs"] < bar["max_abs"] * max(st["ref_std"], 1.0) and st["rel_rms"] < bar["rel_rms"], st
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_pipeline_inpaint_small(dtype):
+    """config-5 path: ControlNet-inpaint + per-step masked blend with re-noised original latents."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline_controlnet_inpainting import IMAGDressing_v1
+    from oracle.ddim import DDIMOracle
+    from oracle.pipeline import denoise
+    p = build_pair(SMALL, seed=5, with_controlnet=True, dtype=dtype)
+    steps, gs = 8, 5.0
+    noise = g(42, 2, 4, 16, 24)
+    pe, ne = g(10, 1, 77, 64, scale=0.5), g(11, 1, 77, 64, scale=0.5)
+    cloth = g(12, 2, 16, 64, scale=0.5); refl = g(13, 1, 4, 16, 16)
+    img_lat = g(17, 1, 4, 16, 24)
+    mask = torch.zeros(1, 1, 16, 24); mask[:, :, 4:12, 6:18] = 1.0              # centred rectangle
+    ctrl = torch.rand(1, 3, 128, 192, generator=torch.Generator().manual_seed(18))
+    refs = [denoise(p["o_unet"], p["o_ref"], DDIMOracle(), noise[i:i + 1], pe, ne, cloth, refl, steps, gs, controlnet=p["o_ctrl"],
+                    control_image=ctrl, prompt_embeds_control=torch.cat([ne, pe]), conditioning_scale=1.0,
+                    inpaint=dict(mask=mask, image_latents=img_lat, noise=noise[i:i + 1])) for i in range(2)]
+    ref = torch.cat(refs)
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           controlnet=p["e_ctrl"], image_encoder=None, ImgProj=lambda h: h, scheduler=_sched())
+    out = pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=192, height=128,
+               num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=2, control_image=ctrl.cuda(),
+               prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(),
+               ref_image_latents=refl.cuda(), image_latents=img_lat.cuda(), mask_latents=mask.cuda(), noise=noise.cuda(),
+               output_type="latent").images
+    st = err_stats(out, ref); record(f"pipeline_inpaint_small[{dtype}]", st)
+    bar = _traj_bar(dtype)
+    assert torch.isfinite(out).all()
+    assert st["max_abs"] < bar["max_abs"] * max(st["ref_std"], 1.0) and st["rel_rms"] < bar["rel_rms"], st
+    # outside the mask the result is exactly the original latents (last step: no re-noising, :494-500)
+    keep = (mask == 0).expand(2, 4, -1, -1)
+    assert torch.allclose(out.cpu()[keep], img_lat.expand(2, -1, -1, -1)[keep], atol=1e-5)
