@@ -29,7 +29,8 @@ class ConvGemmParams(C.Structure):
         ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("rowvec_stride", C.c_int),
         ("res", C.c_void_p), ("out_scale", C.c_float), ("act", C.c_int), ("out_f32", C.c_int),
         ("mode", C.c_int), ("hC", C.c_int), ("hH", C.c_int), ("hD", C.c_int),
-        ("hd", HeadsDest * 3), ("dtype", C.c_int),
+        ("hd", HeadsDest * 3), ("dtype", C.c_int), ("split_k", C.c_int), ("splitk_ws", C.c_void_p),
+        ("x_bytes", C.c_uint32), ("w_bytes", C.c_uint32),
     ]
 
 
@@ -77,7 +78,9 @@ SYMBOLS = {
     "imd_device_check": (C.c_int, [C.c_int]),
     "imd_conv_gemm": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int, C.c_void_p]),
     "imd_conv_gemm_auto_cfg": (C.c_int, [C.c_int, C.c_int]),
+    "imd_conv_gemm_auto_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "imd_attention": (C.c_int, [C.POINTER(AttnParams), C.c_void_p]),
+    "imd_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "imd_attn_padded_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "imd_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p]),
     "imd_groupnorm_workspace_floats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -45,10 +45,21 @@ template <int D> struct AttnCfg {
     static constexpr int VVECS = (D * (KT / 8) + 255) / 256;
 };
 
+typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u;
+__device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+constexpr uint32_t OOB = 0xffffffffu;
+
 template <bool F16, int D, int QW, int MINW>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     using C = AttnCfg<D>;
     using E = El<F16>;
+    // When the V^T tile has pad rows (D < DPV) row D is set to ONE: the P.V MFMA then accumulates the softmax
+    // denominator sum_k P[q][k] in accumulator row D for free (and from the same rounded P as the numerator).
+    constexpr bool LSUM_MFMA = C::DPV > D;
+    constexpr int L_DT = D / 32, L_REG = ((D % 32) & 3) + 4 * (((D % 32) >> 3)), L_HI = ((D % 32) >> 2) & 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -60,12 +71,14 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     const int b = blockIdx.z;
     const int q0 = (blockIdx.x * 4 + wave) * (QW * 32);
 
-    // zero the V^T pad rows (head-dim D..DPV-1) of both LDS buffers once; they are never restaged
+    // V^T pad rows (head-dim D..DPV-1) of both LDS buffers, written once and never restaged: row D = 1, rest 0
     if (C::DPV > D) {
         constexpr int PADV = (C::DPV - D) * (VSTR / 16);
+        const uint32_t one2 = E::pack2(1.0f, 1.0f);
         for (int v = tid; v < 2 * PADV; v += 256) {
             const int bufi = v / PADV, r = v % PADV;
-            *reinterpret_cast<uint4*>(smem + bufi * C::BUF + KT * C::KSTR + D * VSTR + r * 16) = make_uint4(0, 0, 0, 0);
+            const uint32_t w = (r < VSTR / 16) ? one2 : 0u;
+            *reinterpret_cast<uint4*>(smem + bufi * C::BUF + KT * C::KSTR + D * VSTR + r * 16) = make_uint4(w, w, w, w);
         }
     }
 
@@ -87,49 +100,42 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     const int nph = (w2 != 0.f) ? 2 : 1;
 
     f32x16 o[QW][C::NDT];
-    uint32_t o1[QW][C::NDT][8];       // phase-1 result, normalised, packed bf16 (the reference
-                                      // rounds each SDPA output to half precision before the add)
     float m_run[QW], l_run[QW];
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
-        m_run[qb] = -INFINITY; l_run[qb] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) o1[qb][dt][r] = 0u;
-        }
-    }
 
     for (int ph = 0; ph < nph; ++ph) {
+#pragma unroll
+        for (int qb = 0; qb < QW; ++qb) {
+            m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
+        }
         const int L = ph ? p.L2 : p.L1;
         const int LP = ph ? p.L2P : p.L1P;
         const int kvb = ph ? (b / p.kv2_bdiv) : (b / p.kv1_bdiv);
         const bf16_t* kbase = (ph ? p.k2 : p.k1) + (size_t)(kvb * p.H + h) * L * C::DPK;
         const bf16_t* vbase = (ph ? p.v2t : p.v1t) + (size_t)(kvb * p.H + h) * C::DPV * LP;
         const int ntiles = (L + KT - 1) / KT;
+        // buffer descriptors over this (batch, head)'s K rows / V^T rows: tails read as zero, no branches
+        const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, (uint32_t)L * C::DPK * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (uint32_t)D * LP * 2, 0x00020000);
 
         uint4 kreg[C::KVECS], vreg[C::VVECS];
         auto load_tile = [&](int t) {
             const int kt0 = t * KT;
 #pragma unroll
             for (int i = 0; i < C::KVECS; ++i) {
-                const int v = tid + i * 256;
-                const int row = v / (C::DPK / 8), vc = v % (C::DPK / 8);
-                uint4 x = make_uint4(0, 0, 0, 0);
-                if (v < KT * (C::DPK / 8) && kt0 + row < L)
-                    x = *reinterpret_cast<const uint4*>(kbase + (size_t)(kt0 + row) * C::DPK + vc * 8);
-                kreg[i] = x;
+                const int v = tid + i * 256;                       // K tile is one contiguous span of KT rows
+                const bool ok = v < KT * (C::DPK / 8);
+                kreg[i] = buf_load16(rs_k, ok ? (uint32_t)(kt0 * C::DPK * 2 + v * 16) : OOB);
             }
 #pragma unroll
             for (int i = 0; i < C::VVECS; ++i) {
                 const int v = tid + i * 256;
                 const int row = v / (KT / 8), vc = v % (KT / 8);
-                uint4 x = make_uint4(0, 0, 0, 0);
-                if (v < D * (KT / 8))
-                    x = *reinterpret_cast<const uint4*>(vbase + (size_t)row * LP + kt0 + vc * 8);
-                vreg[i] = x;
+                const bool ok = v < D * (KT / 8);
+                vreg[i] = buf_load16(rs_v, ok ? (uint32_t)((row * LP + kt0 + vc * 8) * 2) : OOB);
             }
         };
         auto store_tile = [&](int bufi) {
@@ -160,122 +166,120 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
             const char* Ks = smem + (t & 1) * C::BUF;
             const char* Vs = Ks + KT * C::KSTR;
             const bool ragged = (t + 1) * KT > L;
+
+            // ---- S^T = K Q^T: every K fragment is read from LDS once and used for all QW query blocks ----
+            f32x16 s[QW][2];
+#pragma unroll
+            for (int qb = 0; qb < QW; ++qb)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int tk = 0; tk < C::NKT; ++tk) {
+                    const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kb * 32 * C::KSTR + kfrag + tk * 32);
+#pragma unroll
+                    for (int qb = 0; qb < QW; ++qb) s[qb][kb] = E::mfma(kf, qf[qb][tk], s[qb][kb]);
+                }
+
+            uint4 pf[QW][4];
 #pragma unroll
             for (int qb = 0; qb < QW; ++qb) {
-                // ---- S^T = K Q^T for the two 32-key blocks of the tile ----
-                f32x16 s[2];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-                    for (int tk = 0; tk < C::NKT; ++tk) {
-                        const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kb * 32 * C::KSTR + kfrag + tk * 32);
-                        s[kb] = E::mfma(kf, qf[qb][tk], s[kb]);
-                    }
-                }
                 if (ragged) {     // keys >= L of the last tile contribute nothing
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int key = t * KT + kb * 32 + 8 * hi + (r & 7) + 16 * (r >> 3);
-                            if (key >= L) s[kb][r] = -INFINITY;
+                            if (key >= L) s[qb][kb][r] = -INFINITY;
                         }
                 }
                 // ---- online softmax (base 2; Q carries the scale) ----
-                float mx = s[0][0];
+                float mx = s[qb][0][0];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float m_new = fmaxf(m_run[qb], mx);
-                const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-                m_run[qb] = m_new;
+                // rescale only when some row's running max actually moved (exact: alpha == 1 otherwise)
+                if (__any(m_new != m_run[qb])) {
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                    if (!LSUM_MFMA) l_run[qb] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+                    m_run[qb] = m_new;
+                }
                 float psum = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float pe = __builtin_amdgcn_exp2f(s[kb][r] - m_new);
-                        s[kb][r] = pe;
-                        psum += pe;
+                        const float pe = __builtin_amdgcn_exp2f(s[qb][kb][r] - m_new);
+                        s[qb][kb][r] = pe;
+                        if (!LSUM_MFMA) psum += pe;
                     }
-                l_run[qb] = l_run[qb] * alpha + psum;
-#pragma unroll
-                for (int dt = 0; dt < C::NDT; ++dt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+                if (!LSUM_MFMA) l_run[qb] += psum;
                 // ---- P^T fragments: register octet g of block kb = keys 16g+8hi..+7 of that block ----
-                uint4 pf[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int kb = g >> 1, r0 = (g & 1) * 8;
-                    pf[g].x = E::pack2(s[kb][r0 + 0], s[kb][r0 + 1]);
-                    pf[g].y = E::pack2(s[kb][r0 + 2], s[kb][r0 + 3]);
-                    pf[g].z = E::pack2(s[kb][r0 + 4], s[kb][r0 + 5]);
-                    pf[g].w = E::pack2(s[kb][r0 + 6], s[kb][r0 + 7]);
+                    pf[qb][g].x = E::pack2(s[qb][kb][r0 + 0], s[qb][kb][r0 + 1]);
+                    pf[qb][g].y = E::pack2(s[qb][kb][r0 + 2], s[qb][kb][r0 + 3]);
+                    pf[qb][g].z = E::pack2(s[qb][kb][r0 + 4], s[qb][kb][r0 + 5]);
+                    pf[qb][g].w = E::pack2(s[qb][kb][r0 + 6], s[qb][kb][r0 + 7]);
                 }
-                // ---- O^T += V^T P^T ----
-#pragma unroll
-                for (int dt = 0; dt < C::NDT; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + g * 32);
-                        o[qb][dt] = E::mfma(vf, pf[g], o[qb][dt]);
-                    }
             }
+            // ---- O^T += V^T P^T: every V^T fragment is read once and used for all QW query blocks ----
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + g * 32);
+#pragma unroll
+                    for (int qb = 0; qb < QW; ++qb) o[qb][dt] = E::mfma(vf, pf[qb][g], o[qb][dt]);
+                }
             if (t + 1 < ntiles) store_tile((t + 1) & 1);
             __syncthreads();
         }
 
-        // ---- end of phase: normalise; stash phase 1 when a second phase follows ----
+        // ---- end of phase: normalise and combine.  out = O1/l1 (phase 0) [+ w2 * O2/l2 (phase 1)]; the phase-0
+        // result is parked in the output buffer (rounded to the 16-bit element type, like the reference's two
+        // half-precision SDPA outputs that are added at attention_processor.py:612) and re-read by the SAME lanes.
 #pragma unroll
         for (int qb = 0; qb < QW; ++qb) {
-            const float lt = l_run[qb] + __shfl_xor(l_run[qb], 32);
-            const float inv = 1.0f / lt;
+            float lt;
+            if (LSUM_MFMA) {
+                const float mine = o[qb][L_DT][L_REG];            // accumulator row D lives in lanes with hi == L_HI
+                const float other = __shfl_xor(mine, 32);
+                lt = (hi == L_HI) ? mine : other;
+            } else {
+                lt = l_run[qb] + __shfl_xor(l_run[qb], 32);
+            }
+            const float inv = ((ph == 1) ? w2 : 1.0f) / lt;
+            const int q = q0 + qb * 32 + col;
+            if (q >= p.N) continue;
+            bf16_t* orow = p.out + ((size_t)b * p.N + q) * p.out_ld + h * D;
 #pragma unroll
             for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[qb][dt][r] *= inv;
-            if (ph == 0 && nph == 2) {
+                for (int j = 0; j < 4; ++j) {
+                    const int dd = dt * 32 + 8 * j + 4 * hi;
+                    if (dd >= D) continue;
+                    float v[4];
 #pragma unroll
-                for (int dt = 0; dt < C::NDT; ++dt) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) o1[qb][dt][r] = E::pack2(o[qb][dt][2 * r], o[qb][dt][2 * r + 1]);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[qb][dt][r] = 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = o[qb][dt][4 * j + e] * inv;
+                    if (ph == 1) {
+                        const uint2 prev = *reinterpret_cast<const uint2*>(orow + dd);
+                        v[0] += E::lo(prev.x); v[1] += E::hi(prev.x); v[2] += E::lo(prev.y); v[3] += E::hi(prev.y);
+                    }
+                    *reinterpret_cast<uint2*>(orow + dd) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
                 }
-                m_run[qb] = -INFINITY;
-                l_run[qb] = 0.f;
-            }
         }
-    }
-
-    // ---- epilogue: O = O1 + w2 * O2 (or O1 alone); lane owns query q, 4 consecutive head-dims / quad
-    const float wgt = (nph == 2) ? w2 : 1.0f;
-#pragma unroll
-    for (int qb = 0; qb < QW; ++qb) {
-        const int q = q0 + qb * 32 + col;
-        if (q >= p.N) continue;
-        bf16_t* orow = p.out + ((size_t)b * p.N + q) * p.out_ld + h * D;
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int dd = dt * 32 + 8 * j + 4 * hi;
-                if (dd >= D) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * j + e;
-                    const uint32_t w = o1[qb][dt][r >> 1];
-                    const float first = (r & 1) ? E::hi(w) : E::lo(w);
-                    v[e] = first + wgt * o[qb][dt][r];
-                }
-                *reinterpret_cast<uint2*>(orow + dd) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
-            }
     }
 }
 
@@ -298,6 +302,8 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
+int g_attn_qw40 = 2;   // query blocks per wave for head dim 40 (tuning knob, imd_set_tuning(0, v))
+
 int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }
 
@@ -310,7 +316,9 @@ int imd_launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("attention: unknown dtype %d", p.dtype);
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (p.D) {
-        case 40: return h ? launch_attn<true, 40, 1, 2>(p, s) : launch_attn<false, 40, 1, 2>(p, s);
+        case 40:
+            if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2>(p, s) : launch_attn<false, 40, 2, 2>(p, s);
+            return h ? launch_attn<true, 40, 1, 2>(p, s) : launch_attn<false, 40, 1, 2>(p, s);
         case 64: return h ? launch_attn<true, 64, 1, 2>(p, s) : launch_attn<false, 64, 1, 2>(p, s);
         case 80: return h ? launch_attn<true, 80, 1, 2>(p, s) : launch_attn<false, 80, 1, 2>(p, s);
         case 160: return h ? launch_attn<true, 160, 1, 1>(p, s) : launch_attn<false, 160, 1, 1>(p, s);

@@ -49,7 +49,7 @@ int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream) {
     if (p->mode == IMD_OUT_HEADS) {
         IMD_REQUIRE(p->hC > 0 && p->hH > 0 && p->hD > 0 && p->hC == p->hH * p->hD, "conv_gemm: bad head split C=%d H=%d D=%d", p->hC, p->hH, p->hD);
         IMD_REQUIRE(p->N % p->hC == 0 && p->N / p->hC <= 3, "conv_gemm: N (%d) must be 1..3 splits of %d channels", p->N, p->hC);
-        IMD_REQUIRE(p->hD % 4 == 0, "conv_gemm: head dim must be a multiple of 4");
+        IMD_REQUIRE(p->hD % 8 == 0, "conv_gemm: head dim must be a multiple of 8");
         IMD_REQUIRE(p->act != IMD_ACT_GEGLU && !p->out_f32, "conv_gemm: head-split output excludes GEGLU / fp32 output");
     }
     if (p->act == IMD_ACT_GEGLU) IMD_REQUIRE(!p->out_f32 && !p->res, "conv_gemm: GEGLU excludes fp32 output and residual");
@@ -57,6 +57,7 @@ int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream) {
 }
 
 int imd_conv_gemm_auto_cfg(int M, int N) { return imd_conv_gemm_choose_cfg(M, N); }
+int imd_conv_gemm_auto_split(int M, int N, int K, int cfg) { return imd_conv_gemm_choose_split(M, N, K, cfg < 0 ? imd_conv_gemm_choose_cfg(M, N) : cfg); }
 
 int imd_attention(const imd_attn_params* p, void* stream) {
     IMD_REQUIRE(p != nullptr, "attention: null params");
@@ -64,6 +65,13 @@ int imd_attention(const imd_attn_params* p, void* stream) {
     IMD_REQUIRE((p->k2 == nullptr) == (p->v2t == nullptr), "attention: k2 and v2t must be given together");
     IMD_REQUIRE(p->out_ld >= p->H * p->D && p->out_ld % 4 == 0, "attention: bad out_ld %d", p->out_ld);
     return imd_launch_attention(*p, (hipStream_t)stream);
+}
+
+int imd_set_tuning(int knob, int value) {
+    switch (knob) {
+        case 0: IMD_REQUIRE(value == 1 || value == 2, "set_tuning: attention QW for head dim 40 must be 1 or 2"); g_attn_qw40 = value; return 0;
+        default: return imd_set_error("set_tuning: unknown knob %d", knob);
+    }
 }
 
 int imd_attn_padded_dims(int D, int* dpk, int* dpv) {

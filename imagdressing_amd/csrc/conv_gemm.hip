@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution / linear layer for gfx950 (bf16 MFMA, fp32 accumulate).
+// Implicit-GEMM convolution / linear layer for gfx950 (bf16 / fp16 MFMA, fp32 accumulate).
 //
 //   out[m, n] = epilogue( sum_k A(m, k) * W[n, k] )        m = output pixel / token, n = channel
 //
@@ -7,13 +7,21 @@
 //   simply the [M, K] row-major matrix (taps = 1, H = W = 1).
 // * W is the pre-packed weight [N][K] with k = tap * Cin + ci  (torch Linear layout; conv weights
 //   are repacked once at load time from [Cout][Cin][3][3] to [Cout][ky][kx][Cin]).
-// * Tiles are staged global -> registers -> LDS (double buffered, one barrier per K tile; the
-//   register hop is what lets the gather zero-fill the padding halo), rows padded by 16 B so
-//   that the 16-lane groups of a ds_read_b128 hit 16 distinct 16-B bank slots.
-// * The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows) so that
-//   in the accumulator a lane owns ONE output row m and 4 consecutive channels per register
-//   quad: bias / time-embedding / residual / SiLU / GEGLU / head-split epilogues are all
-//   lane-local and stores are 8-byte packed bf16x4.
+// * Operand tiles are fetched with raw BUFFER loads: the padding halo, the M / N / K tails and
+//   everything else that must read as zero simply gets an out-of-range offset and the hardware
+//   returns 0 -- no branches, no exec masking, 32-bit address arithmetic only.
+// * Tiles are staged global -> registers -> LDS (double buffered, one barrier per K tile), rows
+//   padded by 16 B so that the 16-lane groups of a ds_read_b128 hit 16 distinct 16-B bank slots.
+// * The MFMA is issued "swapped" (A-operand = weight rows, B-operand = activation rows): a lane's
+//   accumulator registers hold 4 consecutive channels of ONE output row.
+// * Epilogue: the fp32 accumulator tile goes through LDS once, after which every thread owns
+//   8 consecutive channels of a row: bias / per-batch time-embedding vector / scale / residual /
+//   SiLU / GELU / GEGLU are applied on 8-wide vectors with all their loads in flight together, and
+//   the result leaves in coalesced 16-byte stores (or, for the head-split mode, straight into the
+//   per-head Q / K / V^T layouts the attention kernel consumes).
+// * Split-K (small-M layers, e.g. the 8x8 and 16x16 ResNet convs at K = 11520..23040): each K
+//   slice writes its fp32 partial tile to a slab; a second tiny kernel sums the slabs in a fixed
+//   order (deterministic) and runs the same epilogue.
 //
 // Reference arithmetic this replaces (diffusers==0.24.0, un-vendored; call sites
 // /root/reference/dressing_sd/pipelines/IMAGDressing_v1_pipeline.py:466,499,511):
@@ -25,12 +33,114 @@
 
 namespace {
 
+typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u;
+
+__device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+constexpr uint32_t OOB = 0xffffffffu;   // any offset past num_records reads as zero
+
+// ------------------------------------------------------------------------------------------
+// shared epilogue on 8 consecutive channels [n, n+8) of row m (nv = number of valid channels: 4 or 8)
+// ------------------------------------------------------------------------------------------
+template <bool F16>
+__device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int m, int n, int nv, int HWo) {
+    using E = El<F16>;
+    const int bi = m / HWo;
+    float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, r0 = b0, r1 = b0;
+    uint4 rr = make_uint4(0, 0, 0, 0);
+    const bool full = nv == 8;
+    // issue every load first (they are independent), consume afterwards
+    if (p.bias) {
+        b0 = *reinterpret_cast<const float4*>(p.bias + n);
+        if (full) b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    }
+    if (p.rowvec) {
+        const float* rv = p.rowvec + (size_t)bi * p.rowvec_stride + n;
+        r0 = *reinterpret_cast<const float4*>(rv);
+        if (full) r1 = *reinterpret_cast<const float4*>(rv + 4);
+    }
+    if (p.res) {
+        const bf16_t* rp = p.res + (size_t)m * p.res_ld + n;
+        if (full) rr = *reinterpret_cast<const uint4*>(rp);
+        else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rr.x = t.x; rr.y = t.y; }
+    }
+    v[0] += b0.x + r0.x; v[1] += b0.y + r0.y; v[2] += b0.z + r0.z; v[3] += b0.w + r0.w;
+    v[4] += b1.x + r1.x; v[5] += b1.y + r1.y; v[6] += b1.z + r1.z; v[7] += b1.w + r1.w;
+    if (p.out_scale != 1.0f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
+    }
+    if (p.res) {
+        float f[8];
+        unpack8<F16>(rr, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += f[e];
+    }
+    if (p.act == ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+    } else if (p.act == ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+    }
+    if (p.mode == OUT_HEADS) {
+        const int which = n / p.hC;
+        const int c = n - which * p.hC;
+        const int h = c / p.hD;
+        const int dd = c - h * p.hD;
+        const int tok = m - bi * HWo;
+        const HeadsDest hdst = p.hd[which];
+        if (hdst.ptr == nullptr) return;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= hdst.scale;
+        if (hdst.kind == 0) {          // [B, H, L, DP] row-major per head
+            bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.L + tok) * hdst.DP + dd;
+            if (full) *reinterpret_cast<uint4*>(dst) = pack8<F16>(v);
+            else *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
+        } else {                       // [B, H, DP, L] transposed (keys contiguous)
+            bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.DP + dd) * hdst.L + tok;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < nv) dst[(size_t)e * hdst.L] = E::fromf(v[e]);
+        }
+    } else if (p.act == ACT_GEGLU) {   // interleaved (value, gate) channel pairs -> nv/2 outputs
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + (n >> 1);
+        const uint32_t o0 = E::pack2(v[0] * gelu_erf_f(v[1]), v[2] * gelu_erf_f(v[3]));
+        if (full) {
+            const uint32_t o1 = E::pack2(v[4] * gelu_erf_f(v[5]), v[6] * gelu_erf_f(v[7]));
+            *reinterpret_cast<uint2*>(dst) = make_uint2(o0, o1);
+        } else {
+            *reinterpret_cast<uint32_t*>(dst) = o0;
+        }
+    } else if (p.out_f32) {
+        float* dst = reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        if (full) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n;
+        if (full) *reinterpret_cast<uint4*>(dst) = pack8<F16>(v);
+        else *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
+    }
+}
+
+template <int BM, int BN, int BK> struct TileCfg {
+    static constexpr int STRIDE = BK * 2 + 16;                 // bytes per LDS operand row
+    static constexpr int MAIN = 2 * (BM + BN) * STRIDE;        // double-buffered operand tiles
+    static constexpr int CLD = BN + 4;                         // fp32 epilogue tile leading dim (floats)
+    static constexpr int EPI = BM * CLD * 4;
+    static constexpr int LDS = MAIN > EPI ? MAIN : EPI;
+};
+
 template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
     using E = El<F16>;
+    using T = TileCfg<BM, BN, BK>;
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
-    constexpr int STRIDE = BK * 2 + 16;        // bytes per LDS row (odd number of 16-B slots)
+    constexpr int STRIDE = T::STRIDE;
     constexpr int VPR = BK / 8;                // 16-B vectors per row
     constexpr int RSTEP = 256 / VPR;           // rows covered by one pass of the 256 threads
     constexpr int A_VECS = BM / RSTEP;
@@ -52,8 +162,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
+    // K range of this split (whole BK tiles)
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int split = blockIdx.y;
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    const int kt_begin = split * per;
+    const int kt_end = min(nk_total, kt_begin + per);
+
     const int kc = tid % VPR;          // this thread's 16-B column inside a K tile
     const int r0 = tid / VPR;          // first row it stages
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, p.w_bytes, 0x00020000);
 
     // ---- per-row gather setup (rows are fixed for the whole K loop) ----
     const int HWo = p.Hout * p.Wout;
@@ -77,35 +197,34 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
             a_yx[i] = 0;
         }
     }
+    uint32_t w_off[W_VECS];            // byte offset of (row n, column kc*8) of W, or OOB
+#pragma unroll
+    for (int i = 0; i < W_VECS; ++i) {
+        const int n = n0 + r0 + i * RSTEP;
+        w_off[i] = (n < p.N) ? (uint32_t)(((size_t)n * p.K + kc * 8) * 2) : OOB;
+    }
 
     uint4 a_reg[A_VECS], w_reg[W_VECS];
 
-    auto load_tile = [&](int k0) {
-        const int k = k0 + kc * 8;
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kc * 8;
         const bool kv = k < p.K;
         int tap = 0, ci = k;
         if (p.taps == 9) { tap = k / p.Cin; ci = k - tap * p.Cin; }
         const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (kv && a_base[i] >= 0) {
-                int iy = (a_yx[i] >> 16) + ky;
-                int ix = (int)(short)(a_yx[i] & 0xffff) + kx;
-                if (iy >= 0 && iy < Hl && ix >= 0 && ix < Wl) {
-                    if (p.ups) { iy >>= 1; ix >>= 1; }
-                    const size_t off = (size_t)(a_base[i] + iy * p.Win + ix) * (size_t)p.x_pix_stride + ci;
-                    v = *reinterpret_cast<const uint4*>(p.x + off);
-                }
-            }
-            a_reg[i] = v;
+            int iy = (a_yx[i] >> 16) + ky;
+            int ix = (int)(short)(a_yx[i] & 0xffff) + kx;
+            const bool ok = kv && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+            if (p.ups) { iy >>= 1; ix >>= 1; }
+            const uint32_t off = (uint32_t)((a_base[i] + iy * p.Win + ix) * p.x_pix_stride + ci) * 2u;
+            a_reg[i] = buf_load16(rs_x, ok ? off : OOB);
         }
 #pragma unroll
         for (int i = 0; i < W_VECS; ++i) {
-            const int n = n0 + r0 + i * RSTEP;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (kv && n < p.N) v = *reinterpret_cast<const uint4*>(p.w + (size_t)n * p.K + k);
-            w_reg[i] = v;
+            const uint32_t off = w_off[i] + (uint32_t)(kt * BK * 2);
+            w_reg[i] = buf_load16(rs_w, (kv && w_off[i] != OOB) ? off : OOB);
         }
     };
     auto store_tile = [&](int buf) {
@@ -127,15 +246,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
     __syncthreads();
 
     const int frag_off = (lane & 31) * STRIDE + (lane >> 5) * 16;
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) load_tile((t + 1) * BK);          // global loads fly during the MFMAs
-        const char* As = smem + (t & 1) * BUF;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int it = kt - kt_begin;
+        if (kt + 1 < kt_end) load_tile(kt + 1);          // global loads fly during the MFMAs
+        const char* As = smem + (it & 1) * BUF;
         const char* Ws = As + BM * STRIDE;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -151,89 +272,86 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
                 for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
         }
-        if (t + 1 < nk) store_tile((t + 1) & 1);
+        if (kt + 1 < kt_end) store_tile((it + 1) & 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns row m, register quads own 4 consecutive channels ----
-    const int hi = lane >> 5;
-    const int col = lane & 31;
+    // ---- accumulators -> LDS (fp32): lane owns row m = col, register quads own 4 consecutive channels ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    {
+        const int hi = lane >> 5;
+        const int col = lane & 31;
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm0 + b * 32 + col;
-        if (m >= p.M) continue;
-        const int bi = m / HWo;          // batch index (per-batch row vector, head split)
+        for (int b = 0; b < TM; ++b)
 #pragma unroll
-        for (int a = 0; a < TN; ++a) {
+            for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn0 + a * 32 + 8 * j + 4 * hi;
-                if (n >= p.N) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[a][b][4 * j + e];
-                if (p.bias) {
-                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                for (int j = 0; j < 4; ++j) {
+                    float* dst = Cs + (wm0 + b * 32 + col) * T::CLD + wn0 + a * 32 + 8 * j + 4 * hi;
+                    *reinterpret_cast<float4*>(dst) = make_float4(acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]);
                 }
-                if (p.rowvec) {
-                    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)bi * p.rowvec_stride + n);
-                    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-                }
-                if (p.out_scale != 1.0f) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= p.out_scale;
-                }
-                if (p.res) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
-                    v[0] += E::lo(rr.x); v[1] += E::hi(rr.x); v[2] += E::lo(rr.y); v[3] += E::hi(rr.y);
-                }
-                if (p.act == ACT_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                }
-                if (p.act == ACT_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
-                }
-                if (p.mode == OUT_HEADS) {
-                    const int which = n / p.hC;
-                    const int c = n - which * p.hC;
-                    const int h = c / p.hD;
-                    const int dd = c - h * p.hD;
-                    const int tok = m - bi * HWo;
-                    const HeadsDest hdst = p.hd[which];
-                    if (hdst.ptr == nullptr) continue;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= hdst.scale;
-                    if (hdst.kind == 0) {          // [B, H, L, DP] row-major per head
-                        bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.L + tok) * hdst.DP + dd;
-                        *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
-                    } else {                       // [B, H, DP, L] transposed (keys contiguous)
-                        bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.DP + dd) * hdst.L + tok;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dst[(size_t)e * hdst.L] = E::fromf(v[e]);
-                    }
-                } else if (p.act == ACT_GEGLU) {   // interleaved (value, gate) channel pairs
-                    const float o0 = v[0] * gelu_erf_f(v[1]);
-                    const float o1 = v[2] * gelu_erf_f(v[3]);
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + (n >> 1);
-                    *reinterpret_cast<uint32_t*>(dst) = E::pack2(o0, o1);
-                } else if (p.out_f32) {
-                    float* dst = reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n;
-                    *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
-                }
+    }
+    __syncthreads();
+
+    // ---- cooperative epilogue: 8 consecutive channels of one row per thread-iteration ----
+    constexpr int CPR = BN / 8;                 // chunks per row
+    constexpr int CHUNKS = BM * CPR;
+    if (p.split_k > 1) {                        // raw fp32 partial tile -> slab [split][M][N]
+        float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
+        for (int c = tid; c < CHUNKS; c += 256) {
+            const int row = c / CPR, cc = (c - row * CPR) * 8;
+            const int m = m0 + row, n = n0 + cc;
+            if (m >= p.M || n >= p.N) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc);
+            const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc + 4);
+            float* dst = slab + (size_t)m * p.N + n;
+            *reinterpret_cast<float4*>(dst) = v0;
+            if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
+        }
+        return;
+    }
+    const bool colmajor = p.mode == OUT_HEADS;  // consecutive threads -> consecutive tokens (coalesces V^T / Q / K rows)
+    for (int c = tid; c < CHUNKS; c += 256) {
+        int row, cc;
+        if (colmajor) { cc = (c / BM) * 8; row = c - (c / BM) * BM; }
+        else { row = c / CPR; cc = (c - row * CPR) * 8; }
+        const int m = m0 + row, n = n0 + cc;
+        if (m >= p.M || n >= p.N) continue;
+        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc);
+        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo);
+    }
+}
+
+// sum the split-K slabs in a fixed order and run the epilogue (row-major outputs only)
+template <bool F16>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams p) {
+    const int HWo = p.Hout * p.Wout;
+    const int cpr = (p.N + 7) / 8;
+    const long total = (long)p.M * cpr;
+    const size_t slab = (size_t)p.M * p.N;
+    for (long c = blockIdx.x * 256L + threadIdx.x; c < total; c += (long)gridDim.x * 256L) {
+        const int m = (int)(c / cpr);
+        const int n = (int)(c - (long)m * cpr) * 8;
+        const int nv = (n + 8 <= p.N) ? 8 : 4;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int s = 0; s < p.split_k; ++s) {
+            const float* src = p.splitk_ws + s * slab + (size_t)m * p.N + n;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            if (nv == 8) {
+                const float4 b = *reinterpret_cast<const float4*>(src + 4);
+                v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
             }
         }
+        epilogue8<F16>(p, v, m, n, nv, HWo);
     }
 }
 
 template <bool F16, int BM, int BN, int BK, int WM, int WN>
 int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
-    constexpr int lds = 2 * (BM + BN) * (BK * 2 + 16);
+    constexpr int lds = TileCfg<BM, BN, BK>::LDS;
     static bool attr_set = false;
     auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN>;
     if (!attr_set) {
@@ -242,32 +360,73 @@ int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     const long mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt)), dim3(256), lds, s, p);
-    return imd_check_launch("conv_gemm");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(256), lds, s, p);
+    int rc = imd_check_launch("conv_gemm");
+    if (rc || p.split_k <= 1) return rc;
+    const long chunks = (long)p.M * ((p.N + 7) / 8);
+    long blocks = (chunks + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel<F16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return imd_check_launch("conv_gemm split-K finish");
+}
+
+int tile_dims(int cfg, int* bm, int* bn) {
+    switch (cfg) {
+        case 0: *bm = 128; *bn = 128; return 0;
+        case 1: *bm = 128; *bn = 64; return 0;
+        case 2: *bm = 64; *bn = 64; return 0;
+        default: return 1;
+    }
 }
 
 }  // namespace
 
 int imd_conv_gemm_choose_cfg(int M, int N) {
     const long b128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (b128 < 192) return 2;
-    if ((N % 128) != 0 && (N % 64) == 0 && N < 640) return 1;
+    if (b128 < 96) return 2;          // tiny problems: smaller tiles fill more CUs
+    if (N <= 64) return 1;
     return 0;
 }
 
-int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s) {
+// number of K slices: only for row-major epilogues on problems whose tile grid cannot fill the chip
+int imd_conv_gemm_choose_split(int M, int N, int K, int cfg) {
+    int bm = 128, bn = 128;
+    tile_dims(cfg, &bm, &bn);
+    const long blocks = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    const int ktiles = (K + 63) / 64;
+    if (blocks >= 200 || ktiles < 32) return 1;
+    long s = (448 + blocks - 1) / blocks;           // aim at ~1.75 blocks per CU
+    if (s > ktiles / 16) s = ktiles / 16;
+    if (s > 8) s = 8;
+    return s < 1 ? 1 : (int)s;
+}
+
+int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
+    ConvGemmParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return imd_set_error("conv_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     if ((p.K % 8) || (p.Cin % 8) || (p.x_pix_stride % 8))
         return imd_set_error("conv_gemm: K (%d), Cin (%d) and pixel stride (%d) must be multiples of 8", p.K, p.Cin, p.x_pix_stride);
     if (p.N % 4) return imd_set_error("conv_gemm: N (%d) must be a multiple of 4", p.N);
     if (p.taps != 1 && p.taps != 9) return imd_set_error("conv_gemm: taps must be 1 or 9 (got %d)", p.taps);
     if (p.K != p.taps * p.Cin) return imd_set_error("conv_gemm: K (%d) != taps*Cin (%d)", p.K, p.taps * p.Cin);
+    if (p.mode == OUT_HEADS && (p.hD % 8)) return imd_set_error("conv_gemm: head dim (%d) must be a multiple of 8", p.hD);
+    if (p.act == ACT_GEGLU && (p.N % 8)) return imd_set_error("conv_gemm: GEGLU needs N %% 8 == 0");
+    const size_t npix = (size_t)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win;
+    const size_t xb = ((npix - 1) * (size_t)p.x_pix_stride + p.Cin) * 2, wb = (size_t)p.N * p.K * 2;
+    if (xb >= 0xffffffffull || wb >= 0xffffffffull) return imd_set_error("conv_gemm: operand larger than 4 GiB");
+    p.x_bytes = (uint32_t)xb;
+    p.w_bytes = (uint32_t)wb;
     if (cfg < 0) cfg = imd_conv_gemm_choose_cfg(p.M, p.N);
+    if (p.split_k < 1) p.split_k = 1;
+    if (p.split_k > 1) {
+        if (p.mode == OUT_HEADS || p.act == ACT_GEGLU) return imd_set_error("conv_gemm: split-K supports row-major epilogues only");
+        if (!p.splitk_ws) return imd_set_error("conv_gemm: split_k = %d needs a workspace", p.split_k);
+    }
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("conv_gemm: unknown dtype %d", p.dtype);
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (cfg) {
         case 0: return h ? launch_cfg<true, 128, 128, 64, 2, 2>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2>(p, s);
-        case 1: return h ? launch_cfg<true, 256, 64, 32, 4, 1>(p, s) : launch_cfg<false, 256, 64, 32, 4, 1>(p, s);
+        case 1: return h ? launch_cfg<true, 128, 64, 64, 2, 2>(p, s) : launch_cfg<false, 128, 64, 64, 2, 2>(p, s);
         case 2: return h ? launch_cfg<true, 64, 64, 64, 2, 2>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2>(p, s);
         default: return imd_set_error("conv_gemm: unknown tile config %d", cfg);
     }

@@ -22,8 +22,10 @@ int imd_set_error(const char* fmt, ...);
 int imd_check_launch(const char* what);
 
 int imd_conv_gemm_choose_cfg(int M, int N);
+int imd_conv_gemm_choose_split(int M, int N, int K, int cfg);
 int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
 int imd_launch_attention(const AttnParams& p, hipStream_t s);
+extern int g_attn_qw40;
 int imd_attn_dpk(int D);
 int imd_attn_dpv(int D);
 int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s);

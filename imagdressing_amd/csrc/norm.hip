@@ -45,14 +45,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormPar
         const int g0 = c0 / cpg;
         const int split = min(8, (g0 + 1) * cpg - c0);   // channels [0,split) -> g0, rest -> g0+1
         if (active && vec < vpp) {
-            for (int pix = pix0 + my_pl; pix < pix1; pix += plan) {
-                const uint4 v = *reinterpret_cast<const uint4*>(p.x + ((size_t)b * p.HW + pix) * p.x_ld + c0);
-                float f[8];
-                unpack8<F16>(v, f);
+            const bf16_t* xb = p.x + (size_t)b * p.HW * p.x_ld + c0;
+            // 4 independent 16-byte loads in flight per thread (memory-level parallelism)
+            for (int pix = pix0 + my_pl; pix < pix1; pix += 4 * plan) {
+                uint4 v[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
-                    else           { s1 += f[e]; q1 += f[e] * f[e]; }
+                for (int u = 0; u < 4; ++u) {
+                    const int px = pix + u * plan;
+                    v[u] = (px < pix1) ? *reinterpret_cast<const uint4*>(xb + (size_t)px * p.x_ld) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float f[8];
+                    unpack8<F16>(v[u], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
+                        else           { s1 += f[e]; q1 += f[e] * f[e]; }
+                    }
                 }
             }
         }
@@ -120,17 +130,29 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormPar
             a[e] = ga;
             sh[e] = p.beta[c0 + e] - s_mean[g] * ga;
         }
-        for (int pix = pix0 + my_pl; pix < pix1; pix += plan) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p.x + ((size_t)b * p.HW + pix) * p.x_ld + c0);
-            float f[8];
-            unpack8<F16>(v, f);
+        const bf16_t* xb = p.x + (size_t)b * p.HW * p.x_ld + c0;
+        bf16_t* yb = p.y + (size_t)b * p.HW * p.y_ld + c0;
+        for (int pix = pix0 + my_pl; pix < pix1; pix += 4 * plan) {
+            uint4 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float y = f[e] * a[e] + sh[e];
-                if (p.silu) y = silu_f(y);
-                f[e] = y;
+            for (int u = 0; u < 4; ++u) {
+                const int px = pix + u * plan;
+                v[u] = (px < pix1) ? *reinterpret_cast<const uint4*>(xb + (size_t)px * p.x_ld) : make_uint4(0, 0, 0, 0);
             }
-            *reinterpret_cast<uint4*>(p.y + ((size_t)b * p.HW + pix) * p.y_ld + c0) = pack8<F16>(f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = pix + u * plan;
+                if (px >= pix1) continue;
+                float f[8];
+                unpack8<F16>(v[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = f[e] * a[e] + sh[e];
+                    if (p.silu) y = silu_f(y);
+                    f[e] = y;
+                }
+                *reinterpret_cast<uint4*>(yb + (size_t)px * p.y_ld) = pack8<F16>(f);
+            }
         }
     }
 }

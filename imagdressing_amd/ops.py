@@ -95,7 +95,7 @@ def conv_gemm(
     bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None, rowvec_stride: int = 0,
     rowvec_off: int = 0, res: Optional[torch.Tensor] = None, res_ld: Optional[int] = None, out_scale: float = 1.0,
     act: int = ACT_NONE, out_f32: bool = False,
-    heads: Optional[dict] = None, cfg: int = -1,
+    heads: Optional[dict] = None, cfg: int = -1, split_k: int = 0,
 ) -> Optional[torch.Tensor]:
     """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
 
@@ -141,20 +141,38 @@ def conv_gemm(
             out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else dt, device=x.device)
         p.out = _dev(out, torch.float32 if out_f32 else dt, "out")
         p.out_ld = n_out if out_ld is None else out_ld
-    L.check(L.load().imd_conv_gemm(C.byref(p), cfg, _stream()))
+    lib = L.load()
+    if split_k == 0:        # auto: K slices only where the tile grid cannot fill the chip
+        split_k = 1 if (heads is not None or act == ACT_GEGLU) else lib.imd_conv_gemm_auto_split(M, N, K, cfg)
+    p.split_k = split_k
+    if split_k > 1:
+        p.splitk_ws = splitk_workspace(split_k * M * N, x.device).data_ptr()
+    L.check(lib.imd_conv_gemm(C.byref(p), cfg, _stream()))
     return out
 
 
+_splitk_ws: Dict[str, torch.Tensor] = {}
+
+
+def splitk_workspace(nfloats: int, device) -> torch.Tensor:
+    """Grow-only fp32 scratch for split-K partial tiles (stream-ordered reuse)."""
+    t = _splitk_ws.get(str(device))
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
+        _splitk_ws[str(device)] = t
+    return t
+
+
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias=None, *, res=None, act=ACT_NONE, out_f32=False, out=None,
-           out_ld=None, res_ld=None, cfg=-1) -> torch.Tensor:
+           out_ld=None, res_ld=None, cfg=-1, split_k=0) -> torch.Tensor:
     M, K = x2d.shape
     N = w.shape[0]
     return conv_gemm(x2d, w, M=M, N=N, Cin=K, bias=bias, res=res, act=act, out_f32=out_f32, out=out,
-                     out_ld=out_ld, res_ld=res_ld, cfg=cfg)
+                     out_ld=out_ld, res_ld=res_ld, cfg=cfg, split_k=split_k)
 
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
-                rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1) -> torch.Tensor:
+                rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0) -> torch.Tensor:
     """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout]."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -163,8 +181,8 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1
     M = B * Ho * Wo
     out = conv_gemm(x, w, M=M, N=Cout, Cin=Cin, taps=taps, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups,
                     bias=bias, rowvec=rowvec, rowvec_stride=rowvec_stride, rowvec_off=rowvec_off, res=res, out_scale=out_scale, act=act,
-                    out_f32=out_f32, cfg=cfg)
-    return out.view(B, Ho, Wo, Cout)
+                    out_f32=out_f32, cfg=cfg, split_k=split_k)
+    return out.view(B, Ho, Wo, -1)
 
 
 # bench.py installs {"match": fn(**shape) -> bool, "events": []} to bracket matching launches with HIP

@@ -60,6 +60,9 @@ typedef struct imd_conv_gemm_params {
     int hC, hH, hD;      /* head split: channels per split, heads, head dim */
     imd_heads_dest hd[3];
     int dtype;           /* IMD_DTYPE_* */
+    int split_k;         /* K slices (<= 1: none); > 1 needs splitk_ws and a row-major epilogue */
+    float* splitk_ws;    /* split_k * M * N floats of scratch */
+    uint32_t x_bytes, w_bytes; /* filled in by the library (buffer-descriptor extents) */
 } imd_conv_gemm_params;
 
 typedef struct imd_attn_params {
@@ -117,9 +120,11 @@ int imd_device_check(int device);
  * ResnetBlock2D.conv1/conv2/conv_shortcut/time_emb_proj, Down/Upsample2D.conv, Transformer2DModel.proj_in/out,
  * Attention.to_q/to_k/to_v/to_out[0], FeedForward (GEGLU), TimestepEmbedding, ControlNet zero-convs; and
  * RefSAttnProcessor2_0.to_k_ref/to_v_ref (adapter/attention_processor.py:600-601), to_k_ip/to_v_ip (:841-842),
- * the nn.Linear layers of adapter/resampler.py.  cfg: -1 auto, 0: 128x128x64, 1: 256x64x32, 2: 64x64x64 tiles. */
+ * the nn.Linear layers of adapter/resampler.py.  cfg: -1 auto, 0: 128x128x64, 1: 128x64x64, 2: 64x64x64 tiles. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);
+/* suggested number of K slices for tile config `cfg` (1 = do not split) */
+int imd_conv_gemm_auto_split(int M, int N, int K, int cfg);
 
 /* Fused dual-softmax attention.  Replaces the two F.scaled_dot_product_attention calls + add of
  * RefSAttnProcessor2_0.__call__ (adapter/attention_processor.py:589-612), LoRAIPAttnProcessor2_0 (:833-856),
@@ -128,6 +133,8 @@ int imd_conv_gemm_auto_cfg(int M, int N);
 int imd_attention(const imd_attn_params* p, void* stream);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
+/* performance knobs (results are identical for every setting).  knob 0: 32-row query blocks per wave for head dim 40 (1|2). */
+int imd_set_tuning(int knob, int value);
 
 /* GroupNorm (+SiLU) over NHWC: diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out. */
 int imd_groupnorm(const imd_groupnorm_params* p, void* stream);

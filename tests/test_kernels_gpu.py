@@ -83,6 +83,30 @@ def test_linear_epilogues(ops, dt):
 
 
 @DTS
+@pytest.mark.parametrize("M,N,K,split,cfg", [(512, 1280, 11520, 6, 0), (200, 320, 2304, 3, 2), (2048, 132, 4096, 4, 1), (64, 64, 8192, 8, -1)])
+def test_linear_split_k(ops, M, N, K, split, cfg, dt):
+    """K slices into fp32 slabs + fixed-order finish kernel == unsplit result (bias + residual + SiLU epilogue)."""
+    x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
+    ref = F.silu(x.float() @ w.float().t() + b + res.float())
+    out = ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=split)
+    assert_close(out, ref, what=f"split-K {split}")
+    one = ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=1)
+    assert_close(out, one.float(), atol=2e-2 if dt == bf16 else 4e-3, what="split vs unsplit")
+    assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=split)), "not deterministic"
+
+
+@DTS
+def test_conv_auto_split_small_m(ops, dt):
+    """the 8x8 ResNet conv shape (M = 512, K = 11520) takes the automatic split-K path"""
+    B, H, W, Cin, Cout = 8, 8, 8, 1280, 1280
+    assert ops.L.load().imd_conv_gemm_auto_split(B * H * W, Cout, 9 * Cin, -1) > 1
+    x = rnd(1, B, Cin, H, W).to(dt); w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt); b = rnd(3, Cout)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1)
+    out = ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b))
+    assert_close(out, ref, what="auto split conv")
+
+
+@DTS
 def test_linear_no_bias_large_k(ops, dt):
     M, N, K = 512, 1280, 11520
     x = rnd(5, M, K).to(dt); w = rnd(6, N, K, scale=K ** -0.5).to(dt)

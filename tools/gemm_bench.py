@@ -58,15 +58,18 @@ def main():
         Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
         M = B * Ho * Wo
         flops = 2.0 * M * Cout * taps * Cin
-        row = dict(shape=name, M=M, N=Cout, K=taps * Cin, auto=ops.L.load().imd_conv_gemm_auto_cfg(M, Cout))
-        for cfg in cfgs:
+        lib = ops.L.load()
+        row = dict(shape=name, M=M, N=Cout, K=taps * Cin, auto=lib.imd_conv_gemm_auto_cfg(M, Cout),
+                   auto_split=lib.imd_conv_gemm_auto_split(M, Cout, taps * Cin, -1) if act != 2 else 1)
+        for cfg in cfgs + [-1]:
             try:
+                sk = 0 if cfg == -1 else 1
                 for _ in range(3):
-                    ops.conv2d_nhwc(x, w, bias, taps=taps, stride=stride, act=act, cfg=cfg)
+                    ops.conv2d_nhwc(x, w, bias, taps=taps, stride=stride, act=act, cfg=cfg, split_k=sk)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(a.iters):
-                    ops.conv2d_nhwc(x, w, bias, taps=taps, stride=stride, act=act, cfg=cfg)
+                    ops.conv2d_nhwc(x, w, bias, taps=taps, stride=stride, act=act, cfg=cfg, split_k=sk)
                 e1.record(); torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / a.iters
                 row[f"cfg{cfg}_us"] = round(us, 1)
