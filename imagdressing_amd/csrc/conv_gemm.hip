@@ -135,7 +135,7 @@ template <int BM, int BN, int BK> struct TileCfg {
 };
 
 template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
     using E = El<F16>;
     using T = TileCfg<BM, BN, BK>;
     constexpr int TM = BM / WAVES_M / 32;
@@ -204,9 +204,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
         w_off[i] = (n < p.N) ? (uint32_t)(((size_t)n * p.K + kc * 8) * 2) : OOB;
     }
 
-    uint4 a_reg[A_VECS], w_reg[W_VECS];
+    // two register staging sets: tile t+1 and t+2 are in flight while tile t is multiplied (global / L2
+    // latency under load is ~2 K-tile times; a single set stalls every iteration on vmcnt)
+    uint4 a_r0[A_VECS], w_r0[W_VECS], a_r1[A_VECS], w_r1[W_VECS];
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, uint4 (&a_reg)[A_VECS], uint4 (&w_reg)[W_VECS]) {
         const int k = kt * BK + kc * 8;
         const bool kv = k < p.K;
         int tap = 0, ci = k;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
             w_reg[i] = buf_load16(rs_w, (kv && w_off[i] != OOB) ? off : OOB);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const uint4 (&a_reg)[A_VECS], const uint4 (&w_reg)[W_VECS]) {
         char* As = smem + buf * BUF;
         char* Ws = As + BM * STRIDE;
 #pragma unroll
@@ -246,17 +248,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-
     const int frag_off = (lane & 31) * STRIDE + (lane >> 5) * 16;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int it = kt - kt_begin;
-        if (kt + 1 < kt_end) load_tile(kt + 1);          // global loads fly during the MFMAs
-        const char* As = smem + (it & 1) * BUF;
+    auto compute = [&](int buf) {
+        const char* As = smem + buf * BUF;
         const char* Ws = As + BM * STRIDE;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
@@ -272,7 +266,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvGemmParams p) 
 #pragma unroll
                 for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
         }
-        if (kt + 1 < kt_end) store_tile((it + 1) & 1);
+    };
+
+    // prologue: tile 0 -> LDS buffer 0, tile 1 in flight in set 1
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin, a_r0, w_r0);
+        if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, a_r1, w_r1);
+        store_tile(0, a_r0, w_r0);
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+        // even tile: multiply LDS buffer 0; set 0 fetches tile kt+2; set 1 (tile kt+1) lands in buffer 1
+        if (kt + 2 < kt_end) load_tile(kt + 2, a_r0, w_r0);
+        compute(0);
+        if (kt + 1 < kt_end) store_tile(1, a_r1, w_r1);
+        __syncthreads();
+        // odd tile: multiply buffer 1; set 1 fetches tile kt+3; set 0 (tile kt+2) lands in buffer 0
+        if (kt + 1 < kt_end) {
+            if (kt + 3 < kt_end) load_tile(kt + 3, a_r1, w_r1);
+            compute(1);
+            if (kt + 2 < kt_end) store_tile(0, a_r0, w_r0);
+        }
         __syncthreads();
     }
 

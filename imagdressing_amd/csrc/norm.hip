@@ -15,9 +15,24 @@
 namespace {
 
 constexpr int GN_THREADS = 320;          // 5 waves: divides evenly for C/8 = 40, 80, 160, 320
-constexpr int GN_PIX_PER_CHUNK = 64;
 
-__device__ __forceinline__ int gn_chunks(int HW) { return (HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK; }
+// pixels per block ("chunk"): sized so that the grid has ~1000 blocks even for the 8x8 / 16x16 levels
+// (a fixed 64-pixel chunk left those launches with 8..32 blocks: pure latency), never below two passes
+// of the block's pixel lanes.
+__host__ __device__ inline int gn_pix_per_chunk(int B, int HW, int C) {
+    const int vpp = C / 8;
+    const int cols = vpp < GN_THREADS ? vpp : GN_THREADS;
+    const int plan = GN_THREADS / cols;
+    int ppc = (int)(((long)B * HW + 1023) / 1024);
+    ppc = (ppc + plan - 1) / plan * plan;
+    if (ppc < 2 * plan) ppc = 2 * plan;
+    if (ppc > 64) ppc = 64;
+    return ppc;
+}
+__host__ __device__ inline int gn_chunks(int B, int HW, int C) {
+    const int ppc = gn_pix_per_chunk(B, HW, C);
+    return (HW + ppc - 1) / ppc;
+}
 
 // One thread: vector column `vec` (channels 8*vec .. 8*vec+7), pixel lanes interleaved.
 template <bool F16>
@@ -27,9 +42,10 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormPar
     const int tid = threadIdx.x;
     const int cpg = p.C / p.G;
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int pix0 = chunk * GN_PIX_PER_CHUNK;
-    const int pix1 = min(p.HW, pix0 + GN_PIX_PER_CHUNK);
-    const int nchunks = gn_chunks(p.HW);
+    const int ppc = gn_pix_per_chunk(p.B, p.HW, p.C);
+    const int pix0 = chunk * ppc;
+    const int pix1 = min(p.HW, pix0 + ppc);
+    const int nchunks = gn_chunks(p.B, p.HW, p.C);
 
     // columns are processed in passes of GN_THREADS / ppb ... keep it simple: loop over
     // column blocks of width `cols` = min(vpp, GN_THREADS); pixel lanes = GN_THREADS / cols.
@@ -98,7 +114,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormPar
     const int tid = threadIdx.x;
     const int cpg = p.C / p.G;
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int nchunks = gn_chunks(p.HW);
+    const int nchunks = gn_chunks(p.B, p.HW, p.C);
     if (tid < p.G) {
         float S = 0.f, Q = 0.f;
         for (int c = 0; c < nchunks; ++c) {
@@ -112,8 +128,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormPar
         s_rstd[tid] = rsqrtf(var + p.eps);
     }
     __syncthreads();
-    const int pix0 = chunk * GN_PIX_PER_CHUNK;
-    const int pix1 = min(p.HW, pix0 + GN_PIX_PER_CHUNK);
+    const int ppc = gn_pix_per_chunk(p.B, p.HW, p.C);
+    const int pix0 = chunk * ppc;
+    const int pix1 = min(p.HW, pix0 + ppc);
     const int cols = min(vpp, GN_THREADS);
     const int plan = GN_THREADS / cols;
     const int my_col = tid % cols, my_pl = tid / cols;
@@ -207,8 +224,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
 }  // namespace
 
 int imd_groupnorm_workspace_floats(int B, int HW, int C, int G) {
-    (void)C;
-    return B * ((HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK) * G * 2;
+    return B * gn_chunks(B, HW, C) * G * 2;
 }
 
 int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
@@ -216,7 +232,7 @@ int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
     if (p.C % 8 || p.C % p.G || p.G > 64) return imd_set_error("groupnorm: C (%d) must be a multiple of 8 and of G (%d <= 64)", p.C, p.G);
     if ((p.C / p.G) < 8) return imd_set_error("groupnorm: channels per group (%d) must be >= 8", p.C / p.G);
     if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("groupnorm: pixel strides must be multiples of 8");
-    const int chunks = (p.HW + GN_PIX_PER_CHUNK - 1) / GN_PIX_PER_CHUNK;
+    const int chunks = gn_chunks(p.B, p.HW, p.C);
     dim3 grid(chunks, p.B);
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("groupnorm: unknown dtype %d", p.dtype);
     const bool h = p.dtype == IMD_DTYPE_F16;
