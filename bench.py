@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=1)
+    ap.add_argument("--attn-qw", type=int, default=0, help="tuning knob 0 of the library (0 = library default)")
     return ap.parse_args()
 
 
@@ -183,6 +184,8 @@ def main():
 
     from imagdressing_amd import dist as imd_dist
     from imagdressing_amd import ops
+    if args.attn_qw:
+        ops.L.check(ops.L.load().imd_set_tuning(0, args.attn_qw))
     pipe = build_pipeline(device, dtype, rank)
     inp = synthetic_inputs(args, device, dtype, rank, world)
     lat_hw = args.res // 8

@@ -41,7 +41,7 @@ class AttnParams(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("D", C.c_int),
         ("L1", C.c_int), ("L1P", C.c_int), ("kv1_bdiv", C.c_int),
         ("L2", C.c_int), ("L2P", C.c_int), ("kv2_bdiv", C.c_int),
-        ("out_ld", C.c_int), ("dtype", C.c_int),
+        ("out_ld", C.c_int), ("dtype", C.c_int), ("flags", C.c_int),
     ]
 
 

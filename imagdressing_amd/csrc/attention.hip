@@ -67,9 +67,25 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     const int wave = tid >> 6;
     const int hi = lane >> 5;
     const int col = lane & 31;
-    const int h = blockIdx.y;
-    const int b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * (QW * 32);
+    // XCD-aware work mapping: hardware block L runs on XCD L % 8 (private 4 MiB L2 each).  Give every XCD a
+    // contiguous slice of the (batch, head, q-tile) work list so that all q-tiles of one (batch, head) -- which
+    // re-read the same K / V^T -- hit the same L2 instead of pulling it through all eight.
+    int wx, h, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, total = gridDim.x * gridDim.y * gridDim.z;
+        const unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned xcd = L & 7u, slot = L >> 3;
+        const unsigned q8 = total >> 3, r8 = total & 7u;          // bijective also when total % 8 != 0
+        unsigned w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        if (p.flags & 1) w = L;                                    // tuning: plain dispatch order
+        // work list order: q-tile fastest, then BATCH, then head -- an XCD's slice then holds whole heads across
+        // all batch rows, i.e. the same mix of 2-phase (garment) and 1-phase rows as every other XCD
+        const unsigned gz = gridDim.z;
+        wx = (int)(w % gx);
+        b = (int)((w / gx) % gz);
+        h = (int)(w / (gx * gz));
+    }
+    const int q0 = (wx * 4 + wave) * (QW * 32);
 
     // V^T pad rows (head-dim D..DPV-1) of both LDS buffers, written once and never restaged: row D = 1, rest 0
     if (C::DPV > D) {
@@ -169,19 +185,15 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 
             // ---- S^T = K Q^T: every K fragment is read from LDS once and used for all QW query blocks ----
             f32x16 s[QW][2];
-#pragma unroll
-            for (int qb = 0; qb < QW; ++qb)
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[qb][kb][r] = 0.f;
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int tk = 0; tk < C::NKT; ++tk) {
                     const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kb * 32 * C::KSTR + kfrag + tk * 32);
 #pragma unroll
-                    for (int qb = 0; qb < QW; ++qb) s[qb][kb] = E::mfma(kf, qf[qb][tk], s[qb][kb]);
+                    for (int qb = 0; qb < QW; ++qb)      // first k step takes the inline constant 0 as C: no accumulator clears
+                        s[qb][kb] = E::mfma(kf, qf[qb][tk], tk == 0 ? zero16 : s[qb][kb]);
                 }
 
             uint4 pf[QW][4];
@@ -302,12 +314,16 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-int g_attn_qw40 = 2;   // query blocks per wave for head dim 40 (tuning knob, imd_set_tuning(0, v))
+int g_attn_qw40 = 1;   // query blocks per wave for head dim 40 (tuning knob, imd_set_tuning(0, v)); 1 measured >= 2
 
 int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }
 
-int imd_launch_attention(const AttnParams& p, hipStream_t s) {
+int g_attn_xcd = 1;
+
+int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
+    AttnParams p = p_in;
+    p.flags = g_attn_xcd ? 0 : 1;
     if (p.B <= 0 || p.H <= 0 || p.N <= 0 || p.L1 <= 0) return imd_set_error("attention: empty problem B=%d H=%d N=%d L1=%d", p.B, p.H, p.N, p.L1);
     if (p.L1P % 64 || p.L1P < p.L1) return imd_set_error("attention: L1P (%d) must be a multiple of 64 and >= L1 (%d)", p.L1P, p.L1);
     if (p.k2 && (p.L2 <= 0 || p.L2P % 64 || p.L2P < p.L2)) return imd_set_error("attention: bad second key set L2=%d L2P=%d", p.L2, p.L2P);

@@ -126,18 +126,21 @@ __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int
     }
 }
 
-template <int BM, int BN, int BK> struct TileCfg {
+template <int BM, int BN, int BK, int WAVES_M> struct TileCfg {
     static constexpr int STRIDE = BK * 2 + 16;                 // bytes per LDS operand row
     static constexpr int MAIN = 2 * (BM + BN) * STRIDE;        // double-buffered operand tiles
     static constexpr int CLD = BN + 4;                         // fp32 epilogue tile leading dim (floats)
-    static constexpr int EPI = BM * CLD * 4;
+    static constexpr int EROWS = BM / WAVES_M;                 // the epilogue goes through LDS one wave-row group at a time
+    static constexpr int EPI = EROWS * CLD * 4;
     static constexpr int LDS = MAIN > EPI ? MAIN : EPI;
 };
 
-template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+// VAR: main-loop schedule.  0 = fragments read per 16-deep k step; 1 = all fragments of the tile read up front
+//      (one LDS latency per tile instead of four) -- needs 64 more VGPRs, only for the 128x128 tile.
+template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int VAR>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
     using E = El<F16>;
-    using T = TileCfg<BM, BN, BK>;
+    using T = TileCfg<BM, BN, BK, WAVES_M>;
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int STRIDE = T::STRIDE;
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     const int Wl = p.ups ? p.Win * 2 : p.Win;
     int a_base[A_VECS];    // pixel index of (b, 0, 0), or -1 when the row is out of range
     int a_yx[A_VECS];      // (iy0 << 16) | (ix0 & 0xffff), top-left tap position
+    int a_lin[A_VECS];     // element offset of the top-left tap (non-upsampled path: tap (ky,kx) adds a uniform delta)
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
         const int m = m0 + r0 + i * RSTEP;
@@ -190,11 +194,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             const int rem = m - b * HWo;
             const int oy = rem / p.Wout;
             const int ox = rem - oy * p.Wout;
+            const int iy0 = oy * p.stride - pad, ix0 = ox * p.stride - pad;
             a_base[i] = b * p.Hin * p.Win;
-            a_yx[i] = (int)(((unsigned)(oy * p.stride - pad)) << 16) | ((ox * p.stride - pad) & 0xffff);
+            a_yx[i] = (int)(((unsigned)iy0) << 16) | (ix0 & 0xffff);
+            a_lin[i] = (a_base[i] + iy0 * p.Win + ix0) * p.x_pix_stride;
         } else {
             a_base[i] = -1;
             a_yx[i] = 0;
+            a_lin[i] = 0;
         }
     }
     uint32_t w_off[W_VECS];            // byte offset of (row n, column kc*8) of W, or OOB
@@ -214,13 +221,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         int tap = 0, ci = k;
         if (p.taps == 9) { tap = k / p.Cin; ci = k - tap * p.Cin; }
         const int ky = tap / 3, kx = tap - ky * 3;
+        const int tap_delta = (ky * p.Win + kx) * p.x_pix_stride + ci;     // same for every row of the tile
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i) {
             int iy = (a_yx[i] >> 16) + ky;
             int ix = (int)(short)(a_yx[i] & 0xffff) + kx;
             const bool ok = kv && a_base[i] >= 0 && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
-            if (p.ups) { iy >>= 1; ix >>= 1; }
-            const uint32_t off = (uint32_t)((a_base[i] + iy * p.Win + ix) * p.x_pix_stride + ci) * 2u;
+            uint32_t off;
+            if (p.ups) {          // fused nearest-2x upsample: source pixel = logical pixel >> 1 (not linear in the tap)
+                off = (uint32_t)((a_base[i] + (iy >> 1) * p.Win + (ix >> 1)) * p.x_pix_stride + ci) * 2u;
+            } else {
+                off = (uint32_t)(a_lin[i] + tap_delta) * 2u;
+            }
             a_reg[i] = buf_load16(rs_x, ok ? off : OOB);
         }
 #pragma unroll
@@ -229,12 +241,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             w_reg[i] = buf_load16(rs_w, (kv && w_off[i] != OOB) ? off : OOB);
         }
     };
-    auto store_tile = [&](int buf, const uint4 (&a_reg)[A_VECS], const uint4 (&w_reg)[W_VECS]) {
+    auto store_a = [&](int buf, const uint4 (&a_reg)[A_VECS]) {
         char* As = smem + buf * BUF;
-        char* Ws = As + BM * STRIDE;
 #pragma unroll
         for (int i = 0; i < A_VECS; ++i)
             *reinterpret_cast<uint4*>(As + (r0 + i * RSTEP) * STRIDE + kc * 16) = a_reg[i];
+    };
+    auto store_w = [&](int buf, const uint4 (&w_reg)[W_VECS]) {
+        char* Ws = smem + buf * BUF + BM * STRIDE;
 #pragma unroll
         for (int i = 0; i < W_VECS; ++i)
             *reinterpret_cast<uint4*>(Ws + (r0 + i * RSTEP) * STRIDE + kc * 16) = w_reg[i];
@@ -249,93 +263,113 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int frag_off = (lane & 31) * STRIDE + (lane >> 5) * 16;
-    auto compute = [&](int buf) {
+    auto mma = [&](int buf, int kk) {           // one 16-deep k step of the LDS tile `buf`
         const char* As = smem + buf * BUF;
         const char* Ws = As + BM * STRIDE;
+        uint4 wf[TN], xf[TM];
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            uint4 wf[TN], xf[TM];
+        for (int a = 0; a < TN; ++a)
+            wf[a] = *reinterpret_cast<const uint4*>(Ws + (wn0 + a * 32) * STRIDE + frag_off + kk * 32);
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
-                wf[a] = *reinterpret_cast<const uint4*>(Ws + (wn0 + a * 32) * STRIDE + frag_off + kk * 32);
+        for (int b = 0; b < TM; ++b)
+            xf[b] = *reinterpret_cast<const uint4*>(As + (wm0 + b * 32) * STRIDE + frag_off + kk * 32);
 #pragma unroll
-            for (int b = 0; b < TM; ++b)
-                xf[b] = *reinterpret_cast<const uint4*>(As + (wm0 + b * 32) * STRIDE + frag_off + kk * 32);
+        for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
+            for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
+    };
+    auto mma_tile = [&](int buf) {
+        if (VAR == 0) {
 #pragma unroll
-                for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
+            for (int kk = 0; kk < BK / 16; ++kk) mma(buf, kk);
+        } else {
+            const char* As = smem + buf * BUF;
+            const char* Ws = As + BM * STRIDE;
+            uint4 wf[BK / 16][TN], xf[BK / 16][TM];
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+                    wf[kk][a] = *reinterpret_cast<const uint4*>(Ws + (wn0 + a * 32) * STRIDE + frag_off + kk * 32);
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    xf[kk][b] = *reinterpret_cast<const uint4*>(As + (wm0 + b * 32) * STRIDE + frag_off + kk * 32);
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk)
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[kk][a], xf[kk][b], acc[a][b]);
         }
     };
 
-    // prologue: tile 0 -> LDS buffer 0, tile 1 in flight in set 1
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin, a_r0, w_r0);
-        if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, a_r1, w_r1);
-        store_tile(0, a_r0, w_r0);
-    }
+    // Software pipeline (tiles past the K range read as zero, so the steady state needs no guards):
+    // LDS buffer b holds tile t (being multiplied); register set (t+1)&1 holds tile t+1 (landed one iteration
+    // ago) and is written to the other LDS buffer after the MFMAs; register set t&1 is refilled with tile t+2.
+    load_tile(kt_begin, a_r0, w_r0);
+    load_tile(kt_begin + 1, a_r1, w_r1);
+    store_a(0, a_r0);
+    store_w(0, w_r0);
     __syncthreads();
 
     for (int kt = kt_begin; kt < kt_end; kt += 2) {
-        // even tile: multiply LDS buffer 0; set 0 fetches tile kt+2; set 1 (tile kt+1) lands in buffer 1
-        if (kt + 2 < kt_end) load_tile(kt + 2, a_r0, w_r0);
-        compute(0);
-        if (kt + 1 < kt_end) store_tile(1, a_r1, w_r1);
+        load_tile(kt + 2, a_r0, w_r0);
+        mma_tile(0);
+        store_a(1, a_r1);
+        store_w(1, w_r1);
         __syncthreads();
-        // odd tile: multiply buffer 1; set 1 fetches tile kt+3; set 0 (tile kt+2) lands in buffer 0
         if (kt + 1 < kt_end) {
-            if (kt + 3 < kt_end) load_tile(kt + 3, a_r1, w_r1);
-            compute(1);
-            if (kt + 2 < kt_end) store_tile(0, a_r0, w_r0);
+            load_tile(kt + 3, a_r1, w_r1);
+            mma_tile(1);
+            store_a(0, a_r0);
+            store_w(0, w_r0);
         }
         __syncthreads();
     }
 
-    // ---- accumulators -> LDS (fp32): lane owns row m = col, register quads own 4 consecutive channels ----
+    // ---- epilogue, one wave-row group (EROWS rows of the tile) at a time: accumulators -> LDS (fp32; lane owns
+    // row m = col, register quads own 4 consecutive channels), then every thread emits 8 consecutive channels
+    // of a row.  Staging only EROWS rows keeps the LDS footprint of the small-BK configurations low.
     float* Cs = reinterpret_cast<float*>(smem);
-    {
-        const int hi = lane >> 5;
-        const int col = lane & 31;
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float* dst = Cs + (wm0 + b * 32 + col) * T::CLD + wn0 + a * 32 + 8 * j + 4 * hi;
-                    *reinterpret_cast<float4*>(dst) = make_float4(acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]);
-                }
-    }
-    __syncthreads();
-
-    // ---- cooperative epilogue: 8 consecutive channels of one row per thread-iteration ----
     constexpr int CPR = BN / 8;                 // chunks per row
-    constexpr int CHUNKS = BM * CPR;
-    if (p.split_k > 1) {                        // raw fp32 partial tile -> slab [split][M][N]
-        float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
+    constexpr int CHUNKS = T::EROWS * CPR;
+    const bool colmajor = p.mode == OUT_HEADS;  // consecutive threads -> consecutive tokens (coalesces V^T / Q / K rows)
+    float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)split * p.M * p.N : nullptr;
+#pragma unroll 1
+    for (int wr = 0; wr < WAVES_M; ++wr) {
+        if (wave / WAVES_N == wr) {
+            const int hi = lane >> 5;
+            const int col = lane & 31;
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* dst = Cs + (b * 32 + col) * T::CLD + wn0 + a * 32 + 8 * j + 4 * hi;
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]);
+                    }
+        }
+        __syncthreads();
         for (int c = tid; c < CHUNKS; c += 256) {
-            const int row = c / CPR, cc = (c - row * CPR) * 8;
-            const int m = m0 + row, n = n0 + cc;
+            int row, cc;
+            if (colmajor) { cc = (c / T::EROWS) * 8; row = c - (c / T::EROWS) * T::EROWS; }
+            else { row = c / CPR; cc = (c - row * CPR) * 8; }
+            const int m = m0 + wr * T::EROWS + row, n = n0 + cc;
             if (m >= p.M || n >= p.N) continue;
             const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc);
             const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc + 4);
-            float* dst = slab + (size_t)m * p.N + n;
-            *reinterpret_cast<float4*>(dst) = v0;
-            if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
+            if (slab) {                         // raw fp32 partial tile -> slab [split][M][N]
+                float* dst = slab + (size_t)m * p.N + n;
+                *reinterpret_cast<float4*>(dst) = v0;
+                if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
+            } else {
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo);
+            }
         }
-        return;
-    }
-    const bool colmajor = p.mode == OUT_HEADS;  // consecutive threads -> consecutive tokens (coalesces V^T / Q / K rows)
-    for (int c = tid; c < CHUNKS; c += 256) {
-        int row, cc;
-        if (colmajor) { cc = (c / BM) * 8; row = c - (c / BM) * BM; }
-        else { row = c / CPR; cc = (c - row * CPR) * 8; }
-        const int m = m0 + row, n = n0 + cc;
-        if (m >= p.M || n >= p.N) continue;
-        const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc);
-        const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc + 4);
-        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-        epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo);
+        if (wr + 1 < WAVES_M) __syncthreads();
     }
 }
 
@@ -364,11 +398,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams
     }
 }
 
-template <bool F16, int BM, int BN, int BK, int WM, int WN>
+template <bool F16, int BM, int BN, int BK, int WM, int WN, int VAR = 0>
 int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
-    constexpr int lds = TileCfg<BM, BN, BK>::LDS;
+    constexpr int lds = TileCfg<BM, BN, BK, WM>::LDS;
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN>;
+    auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN, VAR>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -390,6 +424,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 0: *bm = 128; *bn = 128; return 0;
         case 1: *bm = 128; *bn = 64; return 0;
         case 2: *bm = 64; *bn = 64; return 0;
+        case 3: case 4: *bm = 128; *bn = 128; return 0;
         default: return 1;
     }
 }
@@ -400,6 +435,9 @@ int imd_conv_gemm_choose_cfg(int M, int N) {
     const long b128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (b128 < 96) return 2;          // tiny problems: smaller tiles fill more CUs
     if (N <= 64) return 1;
+    // many tiles (>= ~3 per CU): the 41 KB / 140-VGPR BK=32 variant keeps 3 workgroups per CU resident and wins
+    // (measured on the UNet's level-0 and GEGLU shapes); with fewer tiles the BK=64 variant's longer MFMA runs win.
+    if (b128 >= 700) return 4;
     return 0;
 }
 
@@ -443,6 +481,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 0: return h ? launch_cfg<true, 128, 128, 64, 2, 2>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2>(p, s);
         case 1: return h ? launch_cfg<true, 128, 64, 64, 2, 2>(p, s) : launch_cfg<false, 128, 64, 64, 2, 2>(p, s);
         case 2: return h ? launch_cfg<true, 64, 64, 64, 2, 2>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2>(p, s);
+        case 3: return h ? launch_cfg<true, 128, 128, 64, 2, 2, 1>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2, 1>(p, s);   // experimental schedule
+        case 4: return h ? launch_cfg<true, 128, 128, 32, 2, 2>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2>(p, s);         // 41 KB LDS: 3 workgroups / CU
         default: return imd_set_error("conv_gemm: unknown tile config %d", cfg);
     }
 }

@@ -110,22 +110,34 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormPar
 template <bool F16>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormParams p) {
     __shared__ float s_mean[64], s_rstd[64];
+    __shared__ float red_s[GN_THREADS], red_q[GN_THREADS];
     const int vpp = p.C / 8;
     const int tid = threadIdx.x;
     const int cpg = p.C / p.G;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int nchunks = gn_chunks(p.B, p.HW, p.C);
-    if (tid < p.G) {
+    {   // fold this batch entry's per-chunk partials: ALL threads take part (group = tid % G, every parts-th
+        // chunk each) so the ~100 partial loads of a block are independent and in flight together
+        const int parts = GN_THREADS / p.G;
+        const int g = tid % p.G, part = tid / p.G;
         float S = 0.f, Q = 0.f;
-        for (int c = 0; c < nchunks; ++c) {
-            const float* src = p.partial + (((size_t)b * nchunks + c) * p.G + tid) * 2;
-            S += src[0]; Q += src[1];
+        if (part < parts) {
+            for (int c = part; c < nchunks; c += parts) {
+                const float2 v = *reinterpret_cast<const float2*>(p.partial + (((size_t)b * nchunks + c) * p.G + g) * 2);
+                S += v.x; Q += v.y;
+            }
         }
-        const float n = (float)p.HW * (float)cpg;
-        const float mean = S / n;
-        const float var = fmaxf(Q / n - mean * mean, 0.f);
-        s_mean[tid] = mean;
-        s_rstd[tid] = rsqrtf(var + p.eps);
+        red_s[tid] = S; red_q[tid] = Q;
+        __syncthreads();
+        if (tid < p.G) {
+            float St = 0.f, Qt = 0.f;
+            for (int k = 0; k < parts; ++k) { St += red_s[k * p.G + tid]; Qt += red_q[k * p.G + tid]; }
+            const float n = (float)p.HW * (float)cpg;
+            const float mean = St / n;
+            const float var = fmaxf(Qt / n - mean * mean, 0.f);
+            s_mean[tid] = mean;
+            s_rstd[tid] = rsqrtf(var + p.eps);
+        }
     }
     __syncthreads();
     const int ppc = gn_pix_per_chunk(p.B, p.HW, p.C);

@@ -78,6 +78,7 @@ typedef struct imd_attn_params {
     int L2, L2P, kv2_bdiv;
     int out_ld;
     int dtype;
+    int flags;           /* filled in by the library (tuning bits) */
 } imd_attn_params;
 
 typedef struct imd_groupnorm_params {
@@ -133,7 +134,8 @@ int imd_conv_gemm_auto_split(int M, int N, int K, int cfg);
 int imd_attention(const imd_attn_params* p, void* stream);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
-/* performance knobs (results are identical for every setting).  knob 0: 32-row query blocks per wave for head dim 40 (1|2). */
+/* performance knobs (results are identical for every setting).  knob 0: 32-row query blocks per wave for head dim 40 (1|2);
+ * knob 1: XCD-aware work mapping of the attention grid (0|1). */
 int imd_set_tuning(int knob, int value);
 
 /* GroupNorm (+SiLU) over NHWC: diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out. */

@@ -1,0 +1,52 @@
+"""Micro-benchmark of the fused hybrid-attention kernel at the UNet level-0 shape of the 512x512 CFG batch
+(4 cond rows with the garment branch + 4 uncond rows, N = M = 4096, 8 heads, d = 40) and the other levels.
+Also the target of the PMC passes in tools/pmc_attn.sh (HBM traffic, MFMA busy cycles)."""
+import argparse, json, math, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from imagdressing_amd import ops
+
+def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1):
+    H = 8
+    B = 2 * Bimg
+    dpk, dpv = ops.attn_padded_dims(D)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    def r(*s): return torch.randn(*s, generator=g, device="cuda").to(dt)
+    q = torch.zeros(B, H, N, dpk, dtype=dt, device="cuda"); q[..., :D] = r(B, H, N, D) * (D ** -0.5 * math.log2(math.e))
+    k = torch.zeros(B, H, N, dpk, dtype=dt, device="cuda"); k[..., :D] = r(B, H, N, D)
+    vt = torch.zeros(B, H, dpv, ops.pad64(N), dtype=dt, device="cuda"); vt[:, :, :D, :N] = r(B, H, D, N)
+    kr = torch.zeros(1, H, M, dpk, dtype=dt, device="cuda"); kr[..., :D] = r(1, H, M, D)
+    vr = torch.zeros(1, H, dpv, ops.pad64(M), dtype=dt, device="cuda"); vr[:, :, :D, :M] = r(1, H, D, M)
+    s2 = torch.cat([torch.ones(Bimg), torch.zeros(Bimg)]).cuda()
+    out = torch.empty(B, N, H * D, dtype=dt, device="cuda")
+    if qw is not None:
+        ops.L.check(ops.L.load().imd_set_tuning(0, qw))
+    ops.L.check(ops.L.load().imd_set_tuning(1, xcd))
+    def go():
+        ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B)
+    for _ in range(3): go()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): go()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    C = H * D
+    fl = Bimg * (4.0 * N * N * C + 4.0 * N * M * C) + Bimg * 4.0 * N * N * C
+    # algorithmic HBM bytes: Q,K read + V^T read (D rows) per row, garment K/V once per (cond row, head) from L2/HBM, O written
+    alg_bytes = 2 * (B * H * N * dpk * 2) + B * H * D * N * 2 + H * (M * dpk + D * M) * 2 + B * N * C * 2
+    return dict(D=D, N=N, M=M, Bimg=Bimg, qw=qw, xcd=xcd, us=round(us, 1), tflops=round(fl / us / 1e6, 1), flops=fl, alg_bytes=alg_bytes)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--only-l0", action="store_true")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    cases = [(40, 4096, 4096, 4, 2, 1), (40, 4096, 4096, 4, 1, 1), (40, 4096, 4096, 4, 2, 0), (40, 4096, 4096, 4, 1, 0)]
+    if not a.only_l0:
+        cases += [(80, 1024, 1024, 4, None, 1), (80, 1024, 1024, 4, None, 0), (160, 256, 256, 4, None, 1), (160, 64, 64, 4, None, 1)]
+    for rep in range(2):          # interleaved repeats: within-run A/B
+        for D, N, M, Bi, qw, xcd in cases:
+            print(json.dumps(run(D, N, M, Bi, a.iters, dt, qw, xcd)), flush=True)
+    ops.L.load().imd_set_tuning(0, 1); ops.L.load().imd_set_tuning(1, 1)
