@@ -88,6 +88,26 @@ def pad64(n: int) -> int:
 
 
 # ---------------------------------------------------------------------------------------------
+# Per-shape tile / split-K choices measured on MI355X by tools/gemm_tune.py (like a BLAS tuning file); shapes that
+# are not listed fall back to the library heuristic.  Key: "M,N,K,taps,stride,ups".
+GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
+_GEMM_TABLE = None
+
+
+def _gemm_table() -> dict:
+    global _GEMM_TABLE
+    if _GEMM_TABLE is None:
+        import json
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning.json")
+        try:
+            with open(path) as f:
+                _GEMM_TABLE = json.load(f).get("shapes", {})
+        except FileNotFoundError:
+            _GEMM_TABLE = {}
+    return _GEMM_TABLE
+
+
 def conv_gemm(
     x: torch.Tensor, w: torch.Tensor, *, M: int, N: int, Cin: int, taps: int = 1,
     Hin: int = 1, Win: int = 1, Hout: int = 1, Wout: int = 1, stride: int = 1, ups: bool = False,
@@ -142,8 +162,19 @@ def conv_gemm(
         p.out = _dev(out, torch.float32 if out_f32 else dt, "out")
         p.out_ld = n_out if out_ld is None else out_ld
     lib = L.load()
+    splittable = heads is None and act != ACT_GEGLU
+    if GEMM_TRACE is not None:
+        GEMM_TRACE.append(dict(M=M, N=N, K=K, Cin=Cin, taps=taps, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride,
+                               ups=int(ups), splittable=splittable, dtype=str(dt)))
+    if cfg == -1 and split_k == 0:
+        ent = _gemm_table().get(f"{M},{N},{K},{taps},{stride},{int(ups)}")
+        if ent is not None:
+            if splittable:
+                cfg, split_k = ent["cfg"], ent["split"]
+            else:
+                cfg, split_k = ent["cfg_nosplit"], 1
     if split_k == 0:        # auto: K slices only where the tile grid cannot fill the chip
-        split_k = 1 if (heads is not None or act == ACT_GEGLU) else lib.imd_conv_gemm_auto_split(M, N, K, cfg)
+        split_k = 1 if not splittable else lib.imd_conv_gemm_auto_split(M, N, K, cfg)
     p.split_k = split_k
     if split_k > 1:
         p.splitk_ws = splitk_workspace(split_k * M * N, x.device).data_ptr()

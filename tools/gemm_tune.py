@@ -1,0 +1,103 @@
+"""Per-shape tuning of the implicit-GEMM kernel for the shapes ONE denoising step actually launches.
+
+    python tools/gemm_tune.py [--batch 4 --res 512 --dtype bf16] -> gpurun_out/gemm_tuning.json
+
+Records every conv_gemm shape of one CFG-batched UNet forward (+ the garment pass), times each distinct shape
+with every (tile config, K split) candidate on synthetic operands (interleaved repeats, min of medians), and
+writes the winners.  Copy the result to imagdressing_amd/gemm_tuning.json to use it."""
+import argparse, json, os, statistics, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from imagdressing_amd import ops
+
+CFGS = [0, 4, 2, 1]
+SPLITS = [1, 2, 3, 4, 6]
+
+
+def collect_shapes(args, dt):
+    import bench
+    a = argparse.Namespace(batch=args.batch, res=args.res, ddim_steps=1, dtype=args.dtype)
+    dev = torch.device("cuda", 0)
+    pipe = bench.build_pipeline(dev, dt, 0)
+    inp = bench.synthetic_inputs(a, dev, dt, 0, 1)
+    ops.GEMM_TRACE = []
+    pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=args.res, height=args.res,
+         num_inference_steps=1, guidance_scale=7.5, num_images_per_prompt=args.batch, output_type="latent", **inp)
+    torch.cuda.synchronize()
+    tr, ops.GEMM_TRACE = ops.GEMM_TRACE, None
+    del pipe
+    torch.cuda.empty_cache()
+    uniq = {}
+    for t in tr:
+        key = f"{t['M']},{t['N']},{t['K']},{t['taps']},{t['stride']},{t['ups']}"
+        e = uniq.setdefault(key, dict(t, count=0, any_splittable=False, any_unsplittable=False))
+        e["count"] += 1
+        e["any_splittable"] |= t["splittable"]
+        e["any_unsplittable"] |= not t["splittable"]
+    return uniq
+
+
+def time_candidate(t, cfg, split, dt, iters):
+    B = t["M"] // (t["Hout"] * t["Wout"])
+    x = torch.randn(B, t["Hin"], t["Win"], t["Cin"], device="cuda").to(dt)
+    w = (torch.randn(t["N"], t["K"], device="cuda") * t["K"] ** -0.5).to(dt)
+    bias = torch.randn(t["N"], device="cuda")
+    out = torch.empty(t["M"], t["N"], dtype=dt, device="cuda")
+    def go():
+        ops.conv_gemm(x, w, M=t["M"], N=t["N"], Cin=t["Cin"], taps=t["taps"], Hin=t["Hin"], Win=t["Win"], Hout=t["Hout"],
+                      Wout=t["Wout"], stride=t["stride"], ups=bool(t["ups"]), bias=bias, out=out, cfg=cfg, split_k=split)
+    for _ in range(2):
+        go()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        go()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--out", default="gpurun_out/gemm_tuning.json")
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    shapes = collect_shapes(args, dt)
+    result, log = {}, []
+    total_before = total_after = 0.0
+    for key, t in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
+        flops = 2.0 * t["M"] * t["N"] * t["K"]
+        cands = {}
+        ktiles = (t["K"] + 63) // 64
+        for rep in range(2):
+            for cfg in CFGS:
+                for split in SPLITS:
+                    if split > 1 and (ktiles // split < 8 or not t["any_splittable"]):
+                        continue
+                    try:
+                        us = time_candidate(t, cfg, split, dt, args.iters)
+                    except Exception as ex:          # noqa
+                        continue
+                    cands.setdefault((cfg, split), []).append(us)
+        best = min(cands, key=lambda k: min(cands[k]))
+        best_ns = min((k for k in cands if k[1] == 1), key=lambda k: min(cands[k]))
+        auto_cfg = ops.L.load().imd_conv_gemm_auto_cfg(t["M"], t["N"])
+        auto_split = ops.L.load().imd_conv_gemm_auto_split(t["M"], t["N"], t["K"], auto_cfg) if t["any_splittable"] else 1
+        auto_us = min(cands.get((auto_cfg, auto_split), cands.get((auto_cfg, 1), [float("nan")])))
+        result[key] = dict(cfg=best[0], split=best[1], cfg_nosplit=best_ns[0])
+        total_before += auto_us * t["count"]; total_after += min(cands[best]) * t["count"]
+        log.append(dict(key=key, count=t["count"], best=list(best), best_us=round(min(cands[best]), 1),
+                        best_tf=round(flops / min(cands[best]) / 1e6, 1), heuristic=[auto_cfg, auto_split], heuristic_us=round(auto_us, 1)))
+        print(json.dumps(log[-1]), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        json.dump(dict(note="measured by tools/gemm_tune.py on MI355X", batch=args.batch, res=args.res, dtype=args.dtype,
+                       shapes=result, log=log, total_us_heuristic=round(total_before, 1), total_us_tuned=round(total_after, 1)), f, indent=1)
+    print("total per traced pass: heuristic %.1f us -> tuned %.1f us" % (total_before, total_after))
+
+
+if __name__ == "__main__":
+    main()
