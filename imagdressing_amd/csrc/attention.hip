@@ -59,6 +59,15 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     // When the V^T tile has pad rows (D < DPV) row D is set to ONE: the P.V MFMA then accumulates the softmax
     // denominator sum_k P[q][k] in accumulator row D for free (and from the same rounded P as the numerator).
     constexpr bool LSUM_MFMA = C::DPV > D;
+    // When Q/K rows have pad slots (D < DPK) the running-max subtraction is done BY the QK^T MFMA: K's pad
+    // column D is set to 1 in LDS and Q's pad slot D carries -m_ref, so S comes out as q.k - m_ref and the
+    // softmax needs no per-score subtract.  m_ref is a deferred max: it is raised (and O rescaled) only when a
+    // row's tile maximum exceeds it by more than OFFS_THR (base-2 units), which keeps P <= 2^OFFS_THR.
+    constexpr bool OFFS = C::DPK > D;
+    constexpr float OFFS_THR = 8.0f;
+    constexpr int QPAD_T = D / 16;                    // Q fragment that holds pad slot D ...
+    constexpr int QPAD_HI = (D % 16) / 8;             // ... in the lanes of this half-wave ...
+    static_assert(!OFFS || (D % 8) == 0, "pad slot must start a 16-bit pair");   // ... as element 0 of the fragment
     constexpr int L_DT = D / 32, L_REG = ((D % 32) & 3) + 4 * (((D % 32) >> 3)), L_HI = ((D % 32) >> 2) & 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -121,7 +130,8 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     for (int ph = 0; ph < nph; ++ph) {
 #pragma unroll
         for (int qb = 0; qb < QW; ++qb) {
-            m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+            m_run[qb] = OFFS ? 0.f : -INFINITY; l_run[qb] = 0.f;       // OFFS: m_run is m_ref (starts at 0)
+            if (OFFS && hi == QPAD_HI) qf[qb][QPAD_T].x &= 0xffff0000u;  // Q pad slot = -m_ref = 0
 #pragma unroll
             for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
@@ -161,6 +171,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
             for (int i = 0; i < C::KVECS; ++i) {
                 const int v = tid + i * 256;
                 const int row = v / (C::DPK / 8), vc = v % (C::DPK / 8);
+                if (OFFS && vc == D / 8) kreg[i].x = (kreg[i].x & 0xffff0000u) | (uint32_t)E::fromf(1.0f);   // K[:, D] = 1
                 if (v < KT * (C::DPK / 8)) *reinterpret_cast<uint4*>(Ks + row * C::KSTR + vc * 16) = kreg[i];
             }
 #pragma unroll
@@ -215,27 +226,53 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run[qb], mx);
-                // rescale only when some row's running max actually moved (exact: alpha == 1 otherwise)
-                if (__any(m_new != m_run[qb])) {
-                    const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
-                    if (!LSUM_MFMA) l_run[qb] *= alpha;
+                if (OFFS) {
+                    // s already holds q.k - m_ref.  Raise m_ref only on the first tile or past the threshold.
+                    if (t == 0 || __any(mx > OFFS_THR)) {
+                        const float want = m_run[qb] + ((t == 0) ? mx : fmaxf(mx, 0.f));
+                        const float nref = E::tof(E::fromf(want));          // what the 16-bit Q slot can carry
+                        const float delta = nref - m_run[qb];
+                        if (t != 0) {       // on the first tile O is still 0 (and delta may be hugely negative: 2^-delta = inf)
+                            const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-                    for (int dt = 0; dt < C::NDT; ++dt)
+                            for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
-                    m_run[qb] = m_new;
-                }
-                float psum = 0.f;
+                                for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+                        }
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pe = __builtin_amdgcn_exp2f(s[qb][kb][r] - m_new);
-                        s[qb][kb][r] = pe;
-                        if (!LSUM_MFMA) psum += pe;
+                            for (int r = 0; r < 16; ++r) s[qb][kb][r] -= delta;
+                        m_run[qb] = nref;
+                        if (hi == QPAD_HI) qf[qb][QPAD_T].x = (qf[qb][QPAD_T].x & 0xffff0000u) | (uint32_t)E::fromf(-nref);
                     }
-                if (!LSUM_MFMA) l_run[qb] += psum;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s[qb][kb][r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
+                } else {
+                    const float m_new = fmaxf(m_run[qb], mx);
+                    // rescale only when some row's running max actually moved (exact: alpha == 1 otherwise)
+                    if (__any(m_new != m_run[qb])) {
+                        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+                        if (!LSUM_MFMA) l_run[qb] *= alpha;
+#pragma unroll
+                        for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+                        m_run[qb] = m_new;
+                    }
+                    float psum = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float pe = __builtin_amdgcn_exp2f(s[qb][kb][r] - m_new);
+                            s[qb][kb][r] = pe;
+                            if (!LSUM_MFMA) psum += pe;
+                        }
+                    if (!LSUM_MFMA) l_run[qb] += psum;
+                }
                 // ---- P^T fragments: register octet g of block kb = keys 16g+8hi..+7 of that block ----
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {

@@ -257,6 +257,27 @@ def test_attention_softmax_spike(ops, dt):
     assert_close(out, ref_attn(q, k, v, H), atol=2e-2, what="spike")
 
 
+@DTS
+def test_attention_extreme_logits(ops, dt):
+    """Rows whose logits are all hugely negative (the deferred max must be LOWERED on the first tile, or P underflows
+    to 0 and 0/0 appears) and rows whose logits grow tile after tile (repeated raises of the running reference)."""
+    D, H, B, N, L1 = 40, 8, 1, 64, 320
+    Cc = H * D
+    dpk, dpv = ops.attn_padded_dims(D)
+    q = rnd(1, B, N, Cc).to(dt); k = rnd(2, B, L1, Cc).to(dt); v = rnd(3, B, L1, Cc).to(dt)
+    base = rnd(4, 1, 1, Cc)
+    q[:, :8] = base * 3.0                       # rows 0..7 share a direction ...
+    k[:, :, :] = k * 0.3 - base * 4.0           # ... that every key opposes: all logits << 0 for those rows
+    ramp = torch.linspace(0.0, 6.0, L1).view(1, L1, 1)
+    k[:, :, :] = k + ramp * q[:, 20:21] * 0.2   # row 20 sees logits that keep increasing along the key axis
+    k = k.to(dt)
+    out = torch.empty(B, N, Cc, dtype=dt, device="cuda")
+    ops.attention(dev(to_heads(q, H, dpk, D ** -0.5 * math.log2(math.e), dt=dt)), dev(to_heads(k, H, dpk, dt=dt)),
+                  dev(to_heads_t(v, H, dpv, 320, dt=dt)), out, B=B, H=H, N=N, D=D, L1=L1, L1P=320)
+    assert torch.isfinite(out.float()).all()
+    assert_close(out, ref_attn(q, k, v, H), atol=2e-2, rtol=2e-2, what="extreme logits")
+
+
 # ------------------------------------------------------------------------------------------
 # norms / elementwise
 # ------------------------------------------------------------------------------------------
