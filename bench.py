@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=1)
     ap.add_argument("--attn-qw", type=int, default=0, help="tuning knob 0 of the library (0 = library default)")
+    ap.add_argument("--gemm-flags", type=int, default=-1, help="tuning knob 2 of the library (-1 = library default)")
     return ap.parse_args()
 
 
@@ -186,6 +187,8 @@ def main():
     from imagdressing_amd import ops
     if args.attn_qw:
         ops.L.check(ops.L.load().imd_set_tuning(0, args.attn_qw))
+    if args.gemm_flags >= 0:
+        ops.L.check(ops.L.load().imd_set_tuning(2, args.gemm_flags))
     pipe = build_pipeline(device, dtype, rank)
     inp = synthetic_inputs(args, device, dtype, rank, world)
     lat_hw = args.res // 8
@@ -229,9 +232,14 @@ def main():
             avg_s = sum(ms) / len(ms) * 1e-3
             fl = attn_flops_hybrid_level0(args.batch, N0, N0, 320)
             ach = fl / avg_s / 1e12
+            traffic = None          # HBM bytes per launch from the committed PMC passes of this kernel (same shape only)
+            tpath = os.path.join(ROOT, "profiles", "pmc_r1", "attn_level0_traffic.json")
+            if args.batch == 4 and args.res == 512 and os.path.isfile(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get("traffic_bytes")
             roof = dict(bound="mfma", kernel="attn_kernel<D=40> (fused hybrid attention, UNet level 0, CFG batch)",
                         achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
-                        traffic=None, launches=len(ms), avg_launch_ms=round(avg_s * 1e3, 4), flops_per_launch=fl)
+                        traffic=traffic, launches=len(ms), avg_launch_ms=round(avg_s * 1e3, 4), flops_per_launch=fl)
         line = {
             "metric": "512x512 50-step images/sec (whole node)", "value": round(images / elapsed, 4), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),

@@ -30,7 +30,7 @@ class ConvGemmParams(C.Structure):
         ("res", C.c_void_p), ("out_scale", C.c_float), ("act", C.c_int), ("out_f32", C.c_int),
         ("mode", C.c_int), ("hC", C.c_int), ("hH", C.c_int), ("hD", C.c_int),
         ("hd", HeadsDest * 3), ("dtype", C.c_int), ("split_k", C.c_int), ("splitk_ws", C.c_void_p),
-        ("x_bytes", C.c_uint32), ("w_bytes", C.c_uint32),
+        ("x_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("flags", C.c_int),
     ]
 
 

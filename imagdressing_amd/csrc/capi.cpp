@@ -71,6 +71,7 @@ int imd_set_tuning(int knob, int value) {
     switch (knob) {
         case 0: IMD_REQUIRE(value == 1 || value == 2, "set_tuning: attention QW for head dim 40 must be 1 or 2"); g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
+        case 2: g_gemm_flags = value & 3; return 0;
         default: return imd_set_error("set_tuning: unknown knob %d", knob);
     }
 }

@@ -39,6 +39,12 @@ __device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, ui
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0);
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
+// same, served from L2 without allocating in the CU's 32 KiB vector L1 (sc1): used for the weight stream so that
+// the L1 keeps the activation lines that neighbouring 3x3 taps re-read
+__device__ __forceinline__ uint4 buf_load16_nl1(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
 
 constexpr uint32_t OOB = 0xffffffffu;   // any offset past num_records reads as zero
 
@@ -215,9 +221,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     // latency under load is ~2 K-tile times; a single set stalls every iteration on vmcnt)
     uint4 a_r0[A_VECS], w_r0[W_VECS], a_r1[A_VECS], w_r1[W_VECS];
 
+    // K-tile order.  Default: k = tile * BK (tap-major, channels inner).  "tap-inner" (3x3 convs with Cin % BK == 0):
+    // tile j -> channel chunk j / 9, tap j % 9, so CONSECUTIVE tiles are neighbouring taps of the same channels and
+    // re-read (shifted by one pixel) the activation lines the previous tile just pulled into the L1.
+    const bool tap_inner = (p.flags & 1) != 0;
+    const bool w_bypass_l1 = (p.flags & 2) != 0;
     auto load_tile = [&](int kt, uint4 (&a_reg)[A_VECS], uint4 (&w_reg)[W_VECS]) {
-        const int k = kt * BK + kc * 8;
-        const bool kv = k < p.K;
+        int kbase = kt * BK;
+        if (tap_inner) { const int c = kt / 9; kbase = (kt - 9 * c) * p.Cin + c * BK; }
+        const int k = kbase + kc * 8;
+        const bool kv = (k < p.K) && (kt < nk_total);
         int tap = 0, ci = k;
         if (p.taps == 9) { tap = k / p.Cin; ci = k - tap * p.Cin; }
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -237,8 +250,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         }
 #pragma unroll
         for (int i = 0; i < W_VECS; ++i) {
-            const uint32_t off = w_off[i] + (uint32_t)(kt * BK * 2);
-            w_reg[i] = buf_load16(rs_w, (kv && w_off[i] != OOB) ? off : OOB);
+            const uint32_t off = (kv && w_off[i] != OOB) ? w_off[i] + (uint32_t)(kbase * 2) : OOB;
+            w_reg[i] = w_bypass_l1 ? buf_load16_nl1(rs_w, off) : buf_load16(rs_w, off);
         }
     };
     auto store_a = [&](int buf, const uint4 (&a_reg)[A_VECS]) {
@@ -431,6 +444,8 @@ int tile_dims(int cfg, int* bm, int* bn) {
 
 }  // namespace
 
+int g_gemm_flags = 3;   // tuning knob 2: bit0 tap-inner K order for 3x3 convs, bit1 weight loads bypass L1
+
 int imd_conv_gemm_choose_cfg(int M, int N) {
     const long b128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (b128 < 96) return 2;          // tiny problems: smaller tiles fill more CUs
@@ -471,6 +486,14 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     p.w_bytes = (uint32_t)wb;
     if (cfg < 0) cfg = imd_conv_gemm_choose_cfg(p.M, p.N);
     if (p.split_k < 1) p.split_k = 1;
+    {
+        const int bk = (cfg == 4) ? 32 : 64;
+        p.flags = 0;
+        // measured (profiles/r1g_gemm_flags_ab.jsonl): +8..17 % on the 64x64 / 32x32 feature maps, -2..4 % on 16x16 / 8x8
+        const bool big_map = p.taps == 9 && p.Wout >= 32;
+        if ((g_gemm_flags & 1) && big_map && (p.Cin % bk) == 0) p.flags |= 1;
+        if ((g_gemm_flags & 2) && big_map) p.flags |= 2;
+    }
     if (p.split_k > 1) {
         if (p.mode == OUT_HEADS || p.act == ACT_GEGLU) return imd_set_error("conv_gemm: split-K supports row-major epilogues only");
         if (!p.splitk_ws) return imd_set_error("conv_gemm: split_k = %d needs a workspace", p.split_k);

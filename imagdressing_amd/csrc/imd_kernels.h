@@ -27,6 +27,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
 int imd_launch_attention(const AttnParams& p, hipStream_t s);
 extern int g_attn_qw40;
 extern int g_attn_xcd;
+extern int g_gemm_flags;
 int imd_attn_dpk(int D);
 int imd_attn_dpv(int D);
 int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s);

@@ -63,6 +63,7 @@ typedef struct imd_conv_gemm_params {
     int split_k;         /* K slices (<= 1: none); > 1 needs splitk_ws and a row-major epilogue */
     float* splitk_ws;    /* split_k * M * N floats of scratch */
     uint32_t x_bytes, w_bytes; /* filled in by the library (buffer-descriptor extents) */
+    int flags;           /* filled in by the library (tuning bits) */
 } imd_conv_gemm_params;
 
 typedef struct imd_attn_params {
@@ -135,7 +136,8 @@ int imd_attention(const imd_attn_params* p, void* stream);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
 /* performance knobs (results are identical for every setting).  knob 0: 32-row query blocks per wave for head dim 40 (1|2);
- * knob 1: XCD-aware work mapping of the attention grid (0|1). */
+ * knob 1: XCD-aware work mapping of the attention grid (0|1);
+ * knob 2: GEMM operand-fetch bits (bit0: tap-inner K order for 3x3 convs, bit1: weight loads bypass the L1). */
 int imd_set_tuning(int knob, int value);
 
 /* GroupNorm (+SiLU) over NHWC: diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out. */

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--filter", default="")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--flags", default="3", help="comma list of GEMM tuning flag values to A/B (knob 2)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     cfgs = [int(c) for c in a.cfgs.split(",")]
@@ -61,7 +62,8 @@ def main():
         lib = ops.L.load()
         row = dict(shape=name, M=M, N=Cout, K=taps * Cin, auto=lib.imd_conv_gemm_auto_cfg(M, Cout),
                    auto_split=lib.imd_conv_gemm_auto_split(M, Cout, taps * Cin, -1) if act != 2 else 1)
-        for cfg in cfgs + [-1]:
+        for cfg, fl in [(c, int(f)) for f in a.flags.split(",") for c in cfgs + [-1]]:
+            lib.imd_set_tuning(2, fl)
             try:
                 sk = 0 if cfg == -1 else 1
                 for _ in range(3):
@@ -72,8 +74,8 @@ def main():
                     ops.conv2d_nhwc(x, w, bias, taps=taps, stride=stride, act=act, cfg=cfg, split_k=sk)
                 e1.record(); torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / a.iters
-                row[f"cfg{cfg}_us"] = round(us, 1)
-                row[f"cfg{cfg}_tf"] = round(flops / us / 1e6, 1)
+                row[f"cfg{cfg}_f{fl}_us"] = round(us, 1)
+                row[f"cfg{cfg}_f{fl}_tf"] = round(flops / us / 1e6, 1)
             except Exception as ex:   # noqa
                 row[f"cfg{cfg}_err"] = str(ex)[:80]
         res.append(row)
