@@ -88,6 +88,13 @@ int imd_groupnorm(const imd_groupnorm_params* p, void* stream) {
     return imd_launch_groupnorm(*p, (hipStream_t)stream);
 }
 
+int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* coef_b, void* stream) {
+    IMD_REQUIRE(p && p->x && p->gamma && p->beta && p->partial && coef_a && coef_b, "groupnorm_coeffs: null pointer");
+    return imd_launch_groupnorm_coeffs(*p, coef_a, coef_b, (hipStream_t)stream);
+}
+
+int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (p && imd_conv_patch_supported(*p)) ? 1 : 0; }
+
 int imd_layernorm(const imd_layernorm_params* p, void* stream) {
     IMD_REQUIRE(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
     return imd_launch_layernorm(*p, (hipStream_t)stream);

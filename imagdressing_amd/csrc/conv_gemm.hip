@@ -28,109 +28,9 @@
 // ResnetBlock2D conv1/conv2/conv_shortcut, Down/Upsample2D conv, Transformer2DModel proj_in/
 // proj_out, Attention to_q/to_k/to_v/to_out, GEGLU FeedForward, TimestepEmbedding, and the
 // to_k_ref/to_v_ref garment projections of adapter/attention_processor.py:600-601.
-#include "common.h"
-#include "imd_kernels.h"
+#include "gemm_common.h"
 
 namespace {
-
-typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u;
-
-__device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-// same, served from L2 without allocating in the CU's 32 KiB vector L1 (sc1): used for the weight stream so that
-// the L1 keeps the activation lines that neighbouring 3x3 taps re-read
-__device__ __forceinline__ uint4 buf_load16_nl1(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
-    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
-    return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
-constexpr uint32_t OOB = 0xffffffffu;   // any offset past num_records reads as zero
-
-// ------------------------------------------------------------------------------------------
-// shared epilogue on 8 consecutive channels [n, n+8) of row m (nv = number of valid channels: 4 or 8)
-// ------------------------------------------------------------------------------------------
-template <bool F16>
-__device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int m, int n, int nv, int HWo) {
-    using E = El<F16>;
-    const int bi = m / HWo;
-    float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, r0 = b0, r1 = b0;
-    uint4 rr = make_uint4(0, 0, 0, 0);
-    const bool full = nv == 8;
-    // issue every load first (they are independent), consume afterwards
-    if (p.bias) {
-        b0 = *reinterpret_cast<const float4*>(p.bias + n);
-        if (full) b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-    }
-    if (p.rowvec) {
-        const float* rv = p.rowvec + (size_t)bi * p.rowvec_stride + n;
-        r0 = *reinterpret_cast<const float4*>(rv);
-        if (full) r1 = *reinterpret_cast<const float4*>(rv + 4);
-    }
-    if (p.res) {
-        const bf16_t* rp = p.res + (size_t)m * p.res_ld + n;
-        if (full) rr = *reinterpret_cast<const uint4*>(rp);
-        else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rr.x = t.x; rr.y = t.y; }
-    }
-    v[0] += b0.x + r0.x; v[1] += b0.y + r0.y; v[2] += b0.z + r0.z; v[3] += b0.w + r0.w;
-    v[4] += b1.x + r1.x; v[5] += b1.y + r1.y; v[6] += b1.z + r1.z; v[7] += b1.w + r1.w;
-    if (p.out_scale != 1.0f) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= p.out_scale;
-    }
-    if (p.res) {
-        float f[8];
-        unpack8<F16>(rr, f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += f[e];
-    }
-    if (p.act == ACT_SILU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-    } else if (p.act == ACT_GELU) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-    }
-    if (p.mode == OUT_HEADS) {
-        const int which = n / p.hC;
-        const int c = n - which * p.hC;
-        const int h = c / p.hD;
-        const int dd = c - h * p.hD;
-        const int tok = m - bi * HWo;
-        const HeadsDest hdst = p.hd[which];
-        if (hdst.ptr == nullptr) return;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= hdst.scale;
-        if (hdst.kind == 0) {          // [B, H, L, DP] row-major per head
-            bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.L + tok) * hdst.DP + dd;
-            if (full) *reinterpret_cast<uint4*>(dst) = pack8<F16>(v);
-            else *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
-        } else {                       // [B, H, DP, L] transposed (keys contiguous)
-            bf16_t* dst = hdst.ptr + ((size_t)(bi * p.hH + h) * hdst.DP + dd) * hdst.L + tok;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (e < nv) dst[(size_t)e * hdst.L] = E::fromf(v[e]);
-        }
-    } else if (p.act == ACT_GEGLU) {   // interleaved (value, gate) channel pairs -> nv/2 outputs
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + (n >> 1);
-        const uint32_t o0 = E::pack2(v[0] * gelu_erf_f(v[1]), v[2] * gelu_erf_f(v[3]));
-        if (full) {
-            const uint32_t o1 = E::pack2(v[4] * gelu_erf_f(v[5]), v[6] * gelu_erf_f(v[7]));
-            *reinterpret_cast<uint2*>(dst) = make_uint2(o0, o1);
-        } else {
-            *reinterpret_cast<uint32_t*>(dst) = o0;
-        }
-    } else if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.out) + (size_t)m * p.out_ld + n;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        if (full) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n;
-        if (full) *reinterpret_cast<uint4*>(dst) = pack8<F16>(v);
-        else *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
-    }
-}
 
 template <int BM, int BN, int BK, int WAVES_M> struct TileCfg {
     static constexpr int STRIDE = BK * 2 + 16;                 // bytes per LDS operand row
@@ -437,7 +337,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 0: *bm = 128; *bn = 128; return 0;
         case 1: *bm = 128; *bn = 64; return 0;
         case 2: *bm = 64; *bn = 64; return 0;
-        case 3: case 4: *bm = 128; *bn = 128; return 0;
+        case 3: case 4: case 5: *bm = 128; *bn = 128; return 0;
         default: return 1;
     }
 }
@@ -499,6 +399,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         if (!p.splitk_ws) return imd_set_error("conv_gemm: split_k = %d needs a workspace", p.split_k);
     }
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("conv_gemm: unknown dtype %d", p.dtype);
+    if ((p.gn_a != nullptr) != (p.gn_b != nullptr)) return imd_set_error("conv_gemm: gn_a and gn_b must be given together");
+    if (p.gn_a != nullptr && cfg != 5) return imd_set_error("conv_gemm: the fused GroupNorm prologue needs tile config 5 (got %d)", cfg);
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (cfg) {
         case 0: return h ? launch_cfg<true, 128, 128, 64, 2, 2>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2>(p, s);
@@ -506,6 +408,16 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 2: return h ? launch_cfg<true, 64, 64, 64, 2, 2>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2>(p, s);
         case 3: return h ? launch_cfg<true, 128, 128, 64, 2, 2, 1>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2, 1>(p, s);   // experimental schedule
         case 4: return h ? launch_cfg<true, 128, 128, 32, 2, 2>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2>(p, s);         // 41 KB LDS: 3 workgroups / CU
+        case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
+            int rc = imd_launch_conv_patch(p, s);
+            if (rc || p.split_k <= 1) return rc;
+            const long chunks = (long)p.M * ((p.N + 7) / 8);
+            long blocks = (chunks + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            if (h) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+            return imd_check_launch("conv_patch split-K finish");
+        }
         default: return imd_set_error("conv_gemm: unknown tile config %d", cfg);
     }
 }

@@ -1,0 +1,278 @@
+// 3x3 / stride-1 convolution with the input HALO PATCH resident in LDS (gfx950, bf16 / fp16 MFMA).
+//
+// The gather kernel (conv_gemm.hip) re-fetches the activation tile from L2 for each of the nine taps.  Here a
+// workgroup owns an 8 x 16 block of output pixels of one image x 128 output channels and, per 32-channel chunk,
+// stages the (8+2) x (16+2) input patch in LDS ONCE; the nine taps then read their MFMA operand fragments from
+// that patch at a constant row offset ((ky*18 + kx) rows), so only the weight tile streams per tap.
+// Operand traffic per tap drops from 16 KB to ~9.6 KB and the per-tap address arithmetic disappears.
+//
+// GroupNorm + SiLU fusion: when gn_a / gn_b are given (per-(batch, channel) scale and shift produced from the
+// GroupNorm statistics), the normalisation and the SiLU are applied while the patch is written to LDS -- once per
+// input element instead of as a separate read-modify-write pass over the whole tensor
+// (diffusers ResnetBlock2D: norm -> SiLU -> conv; call sites IMAGDressing_v1_pipeline.py:466,499,511).
+// The zero halo stays zero (padding applies AFTER norm + activation in the reference).
+//
+// Pipeline: A patch double-buffered across channel chunks (fetched during tap 0, written after tap 8), weight tile
+// double-buffered across taps, one barrier per tap; epilogue shared with conv_gemm.hip (bias / time-embedding
+// vector / residual / activation fused, coalesced 16-byte stores); optional split over channel chunks.
+#include <type_traits>
+
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 16;                 // output pixels per workgroup: 8 rows x 16 columns
+constexpr int PW = TW + 2, PH = TH + 2;        // halo patch
+constexpr int NPIX = PH * PW;                  // 180 patch pixels
+constexpr int CK = 32;                         // channels per chunk
+constexpr int RSTR = CK * 2 + 16;              // 80-byte LDS rows (5 x 16 B: odd slot count)
+constexpr int BN = 128;
+constexpr int A_BYTES = NPIX * RSTR;           // 14,400
+constexpr int W_BYTES = BN * RSTR;             // 10,240
+constexpr int MAIN_LDS = 2 * A_BYTES + 2 * W_BYTES;   // 49,280
+constexpr int CLD = BN + 4;
+constexpr int EROWS = 64;
+constexpr int EPI_LDS = EROWS * CLD * 4;       // 33,792
+constexpr int PATCH_LDS = MAIN_LDS > EPI_LDS ? MAIN_LDS : EPI_LDS;
+constexpr int A_VECS = (NPIX * (CK / 8) + 255) / 256;   // 3
+// MFMA column (lane & 31) -> pixel of the wave's 2 x 16 pixel block.  ds_read_b128 is serviced in the 16-lane groups
+// {0-3,12-15,20-27} / {4-11,16-19,28-31}; with the identity mapping the second image row (patch rows +18) lands two
+// lanes of a group on one 16-byte bank slot (2-way conflict on every activation fragment).  This permutation gives
+// each group 16 patch rows that are distinct mod 16, i.e. conflict-free at the 80-byte row stride.
+__device__ constexpr unsigned char kColPix[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7,
+                                                  30, 31, 16, 17, 22, 23, 24, 25, 26, 27, 28, 29, 18, 19, 20, 21};
+constexpr int W_VECS = BN * (CK / 8) / 256;             // 2
+
+template <bool F16>
+__global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmParams p) {
+    using E = El<F16>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Abuf = smem;
+    char* const Wbuf = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm0 = (wave >> 1) * 64;          // 2 x 2 waves, each 64 pixels x 64 channels
+    const int wn0 = (wave & 1) * 64;
+    const int hi = lane >> 5, col = lane & 31;
+    const int cpix = kColPix[col];             // pixel (0..31) this lane's MFMA column stands for
+
+    const int H = p.Hin, W = p.Win;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int n_tiles = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int tile_n = bid % n_tiles; bid /= n_tiles;
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW, n0 = tile_n * BN;
+
+    const int nchunks = p.Cin / CK;
+    const int split = blockIdx.y;
+    const int per = (nchunks + p.split_k - 1) / p.split_k;
+    const int c_begin = split * per;
+    const int c_end = min(nchunks, c_begin + per);
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- per-thread staging assignments ----
+    uint32_t a_off[A_VECS];      // byte offset of (patch pixel, channel 8*vc) at chunk 0, or OOB (halo outside the image)
+    int a_lds[A_VECS];           // LDS byte offset inside an A buffer, or -1
+    int a_ch[A_VECS];            // channel offset 8*vc (for the fused GroupNorm coefficients)
+#pragma unroll
+    for (int i = 0; i < A_VECS; ++i) {
+        const int v = tid + i * 256;
+        const int pp = v / (CK / 8), vc = v % (CK / 8);
+        a_lds[i] = -1; a_off[i] = OOB; a_ch[i] = vc * 8;
+        if (pp < NPIX) {
+            const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
+            a_lds[i] = pp * RSTR + vc * 16;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                a_off[i] = (uint32_t)(((b * H + iy) * W + ix) * p.x_pix_stride + vc * 8) * 2u;
+        }
+    }
+    uint32_t w_off[W_VECS];
+    int w_lds[W_VECS];
+#pragma unroll
+    for (int i = 0; i < W_VECS; ++i) {
+        const int v = tid + i * 256;
+        const int row = v / (CK / 8), vc = v % (CK / 8);
+        w_lds[i] = row * RSTR + vc * 16;
+        w_off[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + vc * 8) * 2) : OOB;
+    }
+
+    // weight tiles are fetched TWO taps ahead into alternating register sets (w_r0 / w_r1): one tap of MFMA work
+    // (~256 matrix-core cycles per wave) is shorter than the L2 latency, two taps x 3 resident workgroups are not
+    uint4 a_reg[A_VECS], w_r0[W_VECS], w_r1[W_VECS];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i)
+            a_reg[i] = buf_load16(rs_x, (a_off[i] != OOB && c < c_end) ? a_off[i] + (uint32_t)(c * CK * 2) : OOB);
+    };
+    auto store_patch = [&](int buf, int c) {
+#pragma unroll
+        for (int i = 0; i < A_VECS; ++i) {
+            if (a_lds[i] < 0) continue;
+            uint4 v = a_reg[i];
+            if (p.gn_a != nullptr && a_off[i] != OOB) {        // fused GroupNorm (+SiLU); the zero halo stays zero
+                const int ch = c * CK + a_ch[i];
+                const float* ga = p.gn_a + (size_t)b * p.Cin + ch;
+                const float* gb = p.gn_b + (size_t)b * p.Cin + ch;
+                const float4 s0 = *reinterpret_cast<const float4*>(ga), s1 = *reinterpret_cast<const float4*>(ga + 4);
+                const float4 t0 = *reinterpret_cast<const float4*>(gb), t1 = *reinterpret_cast<const float4*>(gb + 4);
+                float f[8];
+                unpack8<F16>(v, f);
+                f[0] = fmaf(f[0], s0.x, t0.x); f[1] = fmaf(f[1], s0.y, t0.y); f[2] = fmaf(f[2], s0.z, t0.z); f[3] = fmaf(f[3], s0.w, t0.w);
+                f[4] = fmaf(f[4], s1.x, t1.x); f[5] = fmaf(f[5], s1.y, t1.y); f[6] = fmaf(f[6], s1.z, t1.z); f[7] = fmaf(f[7], s1.w, t1.w);
+                if (p.gn_silu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = silu_f(f[e]);
+                }
+                v = pack8<F16>(f);
+            }
+            *reinterpret_cast<uint4*>(Abuf + buf * A_BYTES + a_lds[i]) = v;
+        }
+    };
+    // it = flattened (chunk, tap) index relative to c_begin; past the end => zero-fill loads that touch no memory
+    const int total = (c_end - c_begin) * 9;
+    auto load_w = [&](uint4 (&wr)[W_VECS], int it) {
+        const int c = c_begin + it / 9, t = it % 9;
+        const uint32_t koff = (uint32_t)((t * p.Cin + c * CK) * 2);
+#pragma unroll
+        for (int i = 0; i < W_VECS; ++i)
+            wr[i] = buf_load16_nl1(rs_w, (w_off[i] != OOB && it < total) ? w_off[i] + koff : OOB);
+    };
+    auto store_w = [&](const uint4 (&wr)[W_VECS], int buf) {
+#pragma unroll
+        for (int i = 0; i < W_VECS; ++i) *reinterpret_cast<uint4*>(Wbuf + buf * W_BYTES + w_lds[i]) = wr[i];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][bb][r] = 0.f;
+
+    // A-fragment base rows: output pixel q = wm0 + bb*32 + col -> patch row (q/16)*18 + q%16 (+ tap offset)
+    int a_frag[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+        const int q = wm0 + bb * 32 + cpix;
+        a_frag[bb] = ((q / TW) * PW + (q % TW)) * RSTR + hi * 16;
+    }
+    const int w_frag = (wn0 + col) * RSTR + hi * 16;
+    // the last channel tile of N = 320 / 960 ... is half empty: waves that own no valid channel skip the matrix work
+    const bool wave_live = n0 + wn0 < p.N;
+
+    if (total > 0) {
+        load_patch(c_begin);
+        load_w(w_r0, 0);
+        load_w(w_r1, 1);
+        store_patch(0, c_begin);
+        store_w(w_r0, 0);
+    }
+    __syncthreads();
+
+    // one tap: prefetch the weights of tap it+2 into `wl`, multiply tap `it` out of W buffer WB, park tap it+1 (`ws`)
+    auto step = [&](int it, auto WBc, uint4 (&wl)[W_VECS], const uint4 (&ws)[W_VECS]) {
+        constexpr int WB = decltype(WBc)::value;
+        const int cc = it / 9, t = it - cc * 9;
+        const int c = c_begin + cc;
+        const int ab = cc & 1;
+        if (t == 0) load_patch(c + 1);       // (before the weight prefetch: vmcnt retires in order)
+        load_w(wl, it + 2);
+        if (wave_live) {
+            const int tap_off = ((t / 3) * PW + (t % 3)) * RSTR;
+            const char* As = Abuf + ab * A_BYTES + tap_off;
+            const char* Ws = Wbuf + WB * W_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < CK / 16; ++kk) {
+                uint4 wf[2], xf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + w_frag + a * 32 * RSTR + kk * 32);
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) xf[bb] = *reinterpret_cast<const uint4*>(As + a_frag[bb] + kk * 32);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) acc[a][bb] = E::mfma(wf[a], xf[bb], acc[a][bb]);
+            }
+        }
+        store_w(ws, WB ^ 1);
+        if (t == 8 && c + 1 < c_end) store_patch(ab ^ 1, c + 1);
+        __syncthreads();
+    };
+#pragma unroll 1
+    for (int it = 0; it < total; it += 2) {
+        step(it, std::integral_constant<int, 0>{}, w_r0, w_r1);
+        if (it + 1 < total) step(it + 1, std::integral_constant<int, 1>{}, w_r1, w_r0);
+    }
+
+    // ---- epilogue (same scheme as conv_gemm.hip): one 64-pixel wave-row group at a time through LDS ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CPR = BN / 8;
+    constexpr int CHUNKS = EROWS * CPR;
+    const int HW = H * W;
+    float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)split * p.M * p.N : nullptr;
+#pragma unroll 1
+    for (int wr = 0; wr < 2; ++wr) {
+        if ((wave >> 1) == wr) {
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* dst = Cs + (bb * 32 + cpix) * CLD + wn0 + a * 32 + 8 * j + 4 * hi;
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[a][bb][4 * j], acc[a][bb][4 * j + 1], acc[a][bb][4 * j + 2], acc[a][bb][4 * j + 3]);
+                    }
+        }
+        __syncthreads();
+        for (int ch = tid; ch < CHUNKS; ch += 256) {
+            const int row = ch / CPR, cc = (ch - row * CPR) * 8;
+            const int q = wr * EROWS + row;
+            const int m = (b * H + y0 + q / TW) * W + x0 + q % TW;
+            const int n = n0 + cc;
+            if (n >= p.N) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
+            const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
+            if (slab) {
+                float* dst = slab + (size_t)m * p.N + n;
+                *reinterpret_cast<float4*>(dst) = v0;
+                if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
+            } else {
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HW);
+            }
+        }
+        if (wr == 0) __syncthreads();
+    }
+}
+
+}  // namespace
+
+bool imd_conv_patch_supported(const ConvGemmParams& p) {
+    return p.taps == 9 && p.stride == 1 && !p.ups && p.Hin == p.Hout && p.Win == p.Wout && (p.Hin % TH) == 0 &&
+           (p.Win % TW) == 0 && (p.Cin % CK) == 0 && p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU;
+}
+
+int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
+    if (!imd_conv_patch_supported(p)) return imd_set_error("conv_patch: unsupported geometry (needs 3x3 stride 1, H %% 8 == 0, W %% 16 == 0, Cin %% 32 == 0)");
+    static bool attr_set[2] = {false, false};
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    const void* kern = h ? reinterpret_cast<const void*>(conv3x3_patch_kernel<true>) : reinterpret_cast<const void*>(conv3x3_patch_kernel<false>);
+    if (!attr_set[h]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_LDS);
+        if (e != hipSuccess) return imd_set_error("conv_patch: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set[h] = true;
+    }
+    const int B = p.M / (p.Hout * p.Wout);
+    const long blocks = (long)B * (p.Hin / TH) * (p.Win / TW) * ((p.N + BN - 1) / BN);
+    if (h) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
+    else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
+    return imd_check_launch("conv_patch");
+}

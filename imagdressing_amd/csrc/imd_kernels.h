@@ -24,6 +24,8 @@ int imd_check_launch(const char* what);
 int imd_conv_gemm_choose_cfg(int M, int N);
 int imd_conv_gemm_choose_split(int M, int N, int K, int cfg);
 int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
+bool imd_conv_patch_supported(const ConvGemmParams& p);
+int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
 int imd_launch_attention(const AttnParams& p, hipStream_t s);
 extern int g_attn_qw40;
 extern int g_attn_xcd;
@@ -31,6 +33,7 @@ extern int g_gemm_flags;
 int imd_attn_dpk(int D);
 int imd_attn_dpv(int D);
 int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s);
+int imd_launch_groupnorm_coeffs(const GroupNormParams& p, float* ca, float* cb, hipStream_t s);
 int imd_launch_layernorm(const LayerNormParams& p, hipStream_t s);
 int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s);
 int imd_launch_timestep_embedding(const float* t, float* out, int B, int dim, hipStream_t s);

@@ -186,6 +186,43 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormPar
     }
 }
 
+// Fold the partials of batch entry blockIdx.x and write the per-(batch, channel) affine form of the normalisation,
+// y = x * a[b][c] + sh[b][c]: consumed by the fused GroupNorm prologue of conv_patch.hip.
+__global__ __launch_bounds__(GN_THREADS) void gn_coeffs_kernel(const GroupNormParams p, float* __restrict__ ca, float* __restrict__ cb) {
+    __shared__ float s_mean[64], s_rstd[64];
+    __shared__ float red_s[GN_THREADS], red_q[GN_THREADS];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int cpg = p.C / p.G;
+    const int nchunks = gn_chunks(p.B, p.HW, p.C);
+    const int parts = GN_THREADS / p.G;
+    const int g = tid % p.G, part = tid / p.G;
+    float S = 0.f, Q = 0.f;
+    if (part < parts) {
+        for (int c = part; c < nchunks; c += parts) {
+            const float2 v = *reinterpret_cast<const float2*>(p.partial + (((size_t)b * nchunks + c) * p.G + g) * 2);
+            S += v.x; Q += v.y;
+        }
+    }
+    red_s[tid] = S; red_q[tid] = Q;
+    __syncthreads();
+    if (tid < p.G) {
+        float St = 0.f, Qt = 0.f;
+        for (int k = 0; k < parts; ++k) { St += red_s[k * p.G + tid]; Qt += red_q[k * p.G + tid]; }
+        const float n = (float)p.HW * (float)cpg;
+        const float mean = St / n;
+        const float var = fmaxf(Qt / n - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < p.C; c += GN_THREADS) {
+        const int gg = c / cpg;
+        const float ga = p.gamma[c] * s_rstd[gg];
+        ca[(size_t)b * p.C + c] = ga;
+        cb[(size_t)b * p.C + c] = p.beta[c] - s_mean[gg] * ga;
+    }
+}
+
 // One wave per row; C <= 8 * 64 * LN_MAXV.
 constexpr int LN_MAXV = 4;
 template <bool F16>
@@ -239,14 +276,32 @@ int imd_groupnorm_workspace_floats(int B, int HW, int C, int G) {
     return B * gn_chunks(B, HW, C) * G * 2;
 }
 
-int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
+static int gn_validate(const GroupNormParams& p) {
     if (p.B <= 0 || p.HW <= 0 || p.C <= 0) return imd_set_error("groupnorm: empty tensor");
     if (p.C % 8 || p.C % p.G || p.G > 64) return imd_set_error("groupnorm: C (%d) must be a multiple of 8 and of G (%d <= 64)", p.C, p.G);
     if ((p.C / p.G) < 8) return imd_set_error("groupnorm: channels per group (%d) must be >= 8", p.C / p.G);
     if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("groupnorm: pixel strides must be multiples of 8");
+    if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("groupnorm: unknown dtype %d", p.dtype);
+    return 0;
+}
+
+int imd_launch_groupnorm_coeffs(const GroupNormParams& p, float* ca, float* cb, hipStream_t s) {
+    int rc = gn_validate(p);
+    if (rc) return rc;
+    dim3 grid(gn_chunks(p.B, p.HW, p.C), p.B);
+    if (p.dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, p);
+    else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, p);
+    rc = imd_check_launch("groupnorm stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_coeffs_kernel, dim3(p.B), dim3(GN_THREADS), 0, s, p, ca, cb);
+    return imd_check_launch("groupnorm coeffs");
+}
+
+int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
+    int rc0 = gn_validate(p);
+    if (rc0) return rc0;
     const int chunks = gn_chunks(p.B, p.HW, p.C);
     dim3 grid(chunks, p.B);
-    if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("groupnorm: unknown dtype %d", p.dtype);
     const bool h = p.dtype == IMD_DTYPE_F16;
     if (h) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, p);
     else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, p);

@@ -90,6 +90,8 @@ def pad64(n: int) -> int:
 # ---------------------------------------------------------------------------------------------
 # Per-shape tile / split-K choices measured on MI355X by tools/gemm_tune.py (like a BLAS tuning file); shapes that
 # are not listed fall back to the library heuristic.  Key: "M,N,K,taps,stride,ups".
+PATCH_CONV = False         # route eligible 3x3 stride-1 convs (W >= PATCH_MIN_W) to the halo-patch kernel (cfg 5)
+PATCH_MIN_W = 32
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 _GEMM_TABLE = None
 
@@ -116,11 +118,14 @@ def conv_gemm(
     rowvec_off: int = 0, res: Optional[torch.Tensor] = None, res_ld: Optional[int] = None, out_scale: float = 1.0,
     act: int = ACT_NONE, out_f32: bool = False,
     heads: Optional[dict] = None, cfg: int = -1, split_k: int = 0,
+    gn: Optional[tuple] = None,
 ) -> Optional[torch.Tensor]:
     """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
 
     ``heads`` = dict(C=, H=, D=, dests=[(tensor|None, kind, DP, L, scale), ...]) selects the head-split
     epilogue (no ``out``).  Returns the output tensor (allocated when ``out`` is None).
+    ``gn`` = (coef_a [B, Cin] fp32, coef_b [B, Cin] fp32, silu) from :func:`group_norm_coeffs` fuses GroupNorm(+SiLU)
+    of the input into the 3x3 halo-patch kernel (tile config 5).
     """
     ensure_device(x.device)
     K = taps * Cin
@@ -162,10 +167,16 @@ def conv_gemm(
         p.out = _dev(out, torch.float32 if out_f32 else dt, "out")
         p.out_ld = n_out if out_ld is None else out_ld
     lib = L.load()
+    if gn is not None:
+        p.gn_a, p.gn_b, p.gn_silu = _dev(gn[0], torch.float32, "gn_a"), _dev(gn[1], torch.float32, "gn_b"), int(gn[2])
+        if cfg == -1:
+            cfg = 5
     splittable = heads is None and act != ACT_GEGLU
     if GEMM_TRACE is not None:
         GEMM_TRACE.append(dict(M=M, N=N, K=K, Cin=Cin, taps=taps, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride,
                                ups=int(ups), splittable=splittable, dtype=str(dt)))
+    if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and not ups and Wout >= PATCH_MIN_W and lib.imd_conv_patch_supported(C.byref(p)):
+        cfg = 5
     if cfg == -1 and split_k == 0:
         ent = _gemm_table().get(f"{M},{N},{K},{taps},{stride},{int(ups)}")
         if ent is not None:
@@ -203,7 +214,7 @@ def linear(x2d: torch.Tensor, w: torch.Tensor, bias=None, *, res=None, act=ACT_N
 
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
-                rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0) -> torch.Tensor:
+                rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0, gn=None) -> torch.Tensor:
     """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout]."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -212,7 +223,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1
     M = B * Ho * Wo
     out = conv_gemm(x, w, M=M, N=Cout, Cin=Cin, taps=taps, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups,
                     bias=bias, rowvec=rowvec, rowvec_stride=rowvec_stride, rowvec_off=rowvec_off, res=res, out_scale=out_scale, act=act,
-                    out_f32=out_f32, cfg=cfg, split_k=split_k)
+                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn)
     return out.view(B, Ho, Wo, -1)
 
 
@@ -266,6 +277,27 @@ def group_norm(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5, silu=False,
     p.eps, p.silu = eps, int(silu)
     L.check(lib.imd_groupnorm(C.byref(p), _stream()))
     return out
+
+
+def group_norm_coeffs(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5):
+    """GroupNorm statistics of x [B, HW, C] as per-(batch, channel) fp32 (a, b) with y = x*a + b: the operand of
+    conv_gemm's fused prologue (``gn=(a, b, silu)``)."""
+    ensure_device(x.device)
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    lib = L.load()
+    nws = lib.imd_groupnorm_workspace_floats(B, HW, Cc, groups)
+    part = workspace("gn_partial", (max(nws, 1),), torch.float32, x.device)
+    ab = torch.empty((2, B, Cc), dtype=torch.float32, device=x.device)
+    p = L.GroupNormParams()
+    p.dtype = _code(x, "x")
+    p.x, p.y = _dev(x, x.dtype, "x"), None
+    p.gamma, p.beta = _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta")
+    p.partial = part.data_ptr()
+    p.B, p.HW, p.C, p.G, p.x_ld, p.y_ld = B, HW, Cc, groups, Cc, Cc
+    p.eps, p.silu = eps, 0
+    L.check(lib.imd_groupnorm_coeffs(C.byref(p), ab[0].data_ptr(), ab[1].data_ptr(), _stream()))
+    return ab[0], ab[1]
 
 
 def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, out=None) -> torch.Tensor:

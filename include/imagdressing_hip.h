@@ -64,6 +64,11 @@ typedef struct imd_conv_gemm_params {
     float* splitk_ws;    /* split_k * M * N floats of scratch */
     uint32_t x_bytes, w_bytes; /* filled in by the library (buffer-descriptor extents) */
     int flags;           /* filled in by the library (tuning bits) */
+    /* fused GroupNorm(+SiLU) prologue (cfg 5 only): x is normalised as x*gn_a[b][c] + gn_b[b][c] (then SiLU when
+     * gn_silu) while it is staged; coefficients come from imd_groupnorm_coeffs().  NULL: plain convolution. */
+    const float* gn_a;
+    const float* gn_b;
+    int gn_silu;
 } imd_conv_gemm_params;
 
 typedef struct imd_attn_params {
@@ -122,7 +127,7 @@ int imd_device_check(int device);
  * ResnetBlock2D.conv1/conv2/conv_shortcut/time_emb_proj, Down/Upsample2D.conv, Transformer2DModel.proj_in/out,
  * Attention.to_q/to_k/to_v/to_out[0], FeedForward (GEGLU), TimestepEmbedding, ControlNet zero-convs; and
  * RefSAttnProcessor2_0.to_k_ref/to_v_ref (adapter/attention_processor.py:600-601), to_k_ip/to_v_ip (:841-842),
- * the nn.Linear layers of adapter/resampler.py.  cfg: -1 auto, 0: 128x128x64, 1: 128x64x64, 2: 64x64x64 tiles. */
+ * the nn.Linear layers of adapter/resampler.py.  cfg: -1 auto, 0: 128x128x64, 1: 128x64x64, 2: 64x64x64, 4: 128x128x32 tiles, 5: 3x3 halo-patch kernel. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);
 /* suggested number of K slices for tile config `cfg` (1 = do not split) */
@@ -143,6 +148,11 @@ int imd_set_tuning(int knob, int value);
 /* GroupNorm (+SiLU) over NHWC: diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out. */
 int imd_groupnorm(const imd_groupnorm_params* p, void* stream);
 int imd_groupnorm_workspace_floats(int B, int HW, int C, int G);
+/* Statistics only: writes the normalisation of ResnetBlock2D.norm1/norm2 as per-(batch, channel) fp32 coefficients
+ * coef_a[B][C], coef_b[B][C] (y = x*a + b; p->y is unused) for imd_conv_gemm's fused prologue (gn_a / gn_b, cfg 5). */
+int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* coef_b, void* stream);
+/* 1 iff tile config 5 (LDS-resident halo patch: 3x3, stride 1, H % 8 == 0, W % 16 == 0, Cin % 32 == 0) can run *p. */
+int imd_conv_patch_supported(const imd_conv_gemm_params* p);
 
 /* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3; adapter/resampler.py:16,43-44,199. */
 int imd_layernorm(const imd_layernorm_params* p, void* stream);

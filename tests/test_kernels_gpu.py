@@ -139,6 +139,45 @@ def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups, dt):
     assert_close(out, ref, what=f"conv3x3 cfg={cfg}")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,split", [
+    (2, 16, 16, 64, 64, 1), (1, 8, 32, 32, 320, 1), (3, 24, 16, 96, 132, 1), (1, 32, 32, 320, 320, 1), (2, 16, 16, 640, 256, 4),
+    (1, 8, 16, 1280, 128, 8)])
+@DTS
+def test_conv3x3_halo_patch(ops, B, H, W, Cin, Cout, split, dt):
+    """tile config 5 (LDS-resident halo patch) == F.conv2d, with the full epilogue and with K slices"""
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, H, W, Cout).to(dt)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1).permute(0, 2, 3, 1) + temb[:, None, None, :] + res.float()
+    out = ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), rowvec=dev(temb), rowvec_stride=Cout,
+                          res=dev(res), cfg=5, split_k=split)
+    assert_close(out, ref, what=f"halo-patch conv split={split}")
+    with pytest.raises(ops.L.ImdError):
+        ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), stride=2, cfg=5)
+
+
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (2, 32, 32, 320, 320), (1, 16, 32, 960, 640)])
+@DTS
+def test_conv3x3_fused_groupnorm(ops, B, H, W, Cin, Cout, silu, dt):
+    """GroupNorm(+SiLU) fused into the conv's patch staging == GroupNorm -> SiLU -> conv (zero padding AFTER the activation)"""
+    x = (rnd(1, B, Cin, H, W) * 1.5 + 0.3).to(dt)
+    gamma = 1.0 + 0.2 * rnd(6, Cin); beta = 0.2 * rnd(7, Cin)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt); b = rnd(3, Cout)
+    G = 32 if Cin >= 256 else 8
+    h = F.group_norm(x.float(), G, gamma, beta, eps=1e-5)
+    if silu:
+        h = F.silu(h)
+    ref = F.conv2d(h.to(dt).float(), w.float(), b, padding=1).permute(0, 2, 3, 1)
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    ca, cb = ops.group_norm_coeffs(xd, dev(gamma), dev(beta), groups=G, eps=1e-5)
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), gn=(ca, cb, silu))
+    assert_close(out, ref, atol=2 * TOL[dt], what="fused GN conv")
+    # and against the unfused HIP path (same rounding points)
+    two = ops.conv2d_nhwc(ops.group_norm(xd, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=silu), dev(pack_conv(w)), dev(b), cfg=0)
+    assert_close(out, two.float(), atol=2 * TOL[dt], what="fused vs unfused")
+
+
 @DTS
 def test_conv_epilogue_rowvec_residual_scale(ops, dt):
     B, H, W, Cin, Cout = 2, 8, 8, 64, 128
