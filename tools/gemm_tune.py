@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from imagdressing_amd import ops
 
-CFGS = [0, 4, 2, 1]
+CFGS = [0, 4, 2, 1, 5]
 SPLITS = [1, 2, 3, 4, 6]
 
 
@@ -63,17 +63,25 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--out", default="gpurun_out/gemm_tuning.json")
+    ap.add_argument("--only-conv3x3", action="store_true",
+                    help="re-time only the 3x3 stride-1 convolutions (candidates 0, 4, 5) and merge into the shipped table")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     shapes = collect_shapes(args, dt)
     result, log = {}, []
+    cfgs = CFGS
+    if args.only_conv3x3:
+        with open(os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "gemm_tuning.json")) as f:
+            result = json.load(f).get("shapes", {})
+        shapes = {k: t for k, t in shapes.items() if t["taps"] == 9 and t["stride"] == 1 and not t["ups"] and t["Cin"] % 32 == 0}
+        cfgs = [0, 4, 5]
     total_before = total_after = 0.0
     for key, t in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
         flops = 2.0 * t["M"] * t["N"] * t["K"]
         cands = {}
         ktiles = (t["K"] + 63) // 64
         for rep in range(2):
-            for cfg in CFGS:
+            for cfg in cfgs:
                 for split in SPLITS:
                     if split > 1 and (ktiles // split < 8 or not t["any_splittable"]):
                         continue
