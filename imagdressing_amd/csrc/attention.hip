@@ -40,7 +40,14 @@ template <int D> struct AttnCfg {
     static constexpr int NKT = DPK / 16;
     static constexpr int NDT = DPV / 32;
     static constexpr int KSTR = DPK * 2 + 16;
-    static constexpr int BUF = KT * KSTR + DPV * VSTR;
+    // V^T rows kept in LDS: the D real rows plus (when D < DPV) the all-ones row D that yields the softmax denominator.
+    // The remaining pad rows of the last 32-row MFMA block are NOT stored: their fragment reads run into the K tile
+    // that follows (finite garbage in, accumulator rows nobody reads out) -- 26 KB instead of 32 KB per workgroup for
+    // d = 40, i.e. 6 resident workgroups per CU instead of 5.
+    static constexpr int VROWS = DPV > D ? D + 1 : DPV;
+    static constexpr int VBYTES = VROWS * VSTR;
+    static constexpr int BUF = VBYTES + KT * KSTR;               // [V^T rows][K rows]
+    static_assert((DPV - VROWS) * VSTR <= KT * KSTR, "phantom V^T rows must stay inside the K tile");
     static constexpr int KVECS = (KT * (DPK / 8) + 255) / 256;
     static constexpr int VVECS = (D * (KT / 8) + 255) / 256;
 };
@@ -52,7 +59,15 @@ __device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, ui
 }
 constexpr uint32_t OOB = 0xffffffffu;
 
-template <bool F16, int D, int QW, int MINW>
+// packed 3-input maximum of two fp16 lanes: on non-negative 16-bit float patterns (fp16 OR bf16) it is the maximum of
+// the patterns as integers, with inf / NaN patterns propagating
+__device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+template <bool F16, int D, int QW, int MINW, int KB, bool SPEC>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     using C = AttnCfg<D>;
     using E = El<F16>;
@@ -96,14 +111,13 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     }
     const int q0 = (wx * 4 + wave) * (QW * 32);
 
-    // V^T pad rows (head-dim D..DPV-1) of both LDS buffers, written once and never restaged: row D = 1, rest 0
+    // V^T row D (the all-ones row) of both LDS buffers, written once and never restaged
     if (C::DPV > D) {
-        constexpr int PADV = (C::DPV - D) * (VSTR / 16);
+        constexpr int PADV = VSTR / 16;
         const uint32_t one2 = E::pack2(1.0f, 1.0f);
         for (int v = tid; v < 2 * PADV; v += 256) {
             const int bufi = v / PADV, r = v % PADV;
-            const uint32_t w = (r < VSTR / 16) ? one2 : 0u;
-            *reinterpret_cast<uint4*>(smem + bufi * C::BUF + KT * C::KSTR + D * VSTR + r * 16) = make_uint4(w, w, w, w);
+            *reinterpret_cast<uint4*>(smem + bufi * C::BUF + D * VSTR + r * 16) = make_uint4(one2, one2, one2, one2);
         }
     }
 
@@ -165,8 +179,8 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
             }
         };
         auto store_tile = [&](int bufi) {
-            char* Ks = smem + bufi * C::BUF;
-            char* Vs = Ks + KT * C::KSTR;
+            char* Vs = smem + bufi * C::BUF;
+            char* Ks = Vs + C::VBYTES;
 #pragma unroll
             for (int i = 0; i < C::KVECS; ++i) {
                 const int v = tid + i * 256;
@@ -190,49 +204,103 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
         const int vfrag = col * VSTR + hi * 16;
         for (int t = 0; t < ntiles; ++t) {
             if (t + 1 < ntiles) load_tile(t + 1);
-            const char* Ks = smem + (t & 1) * C::BUF;
-            const char* Vs = Ks + KT * C::KSTR;
+            const char* Vs = smem + (t & 1) * C::BUF;
+            const char* Ks = Vs + C::VBYTES;
             const bool ragged = (t + 1) * KT > L;
 
-            // ---- S^T = K Q^T: every K fragment is read from LDS once and used for all QW query blocks ----
-            f32x16 s[QW][2];
+            // The 64-key tile is consumed KB 32-key blocks at a time (KB = 2: one softmax update per tile, more
+            // independent MFMAs in flight; KB = 1: half the live S / P registers -> one more resident wave per SIMD).
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int k0 = 0; k0 < 2; k0 += KB) {
+            // ---- S^T = K Q^T: every K fragment is read from LDS once and used for all QW query blocks ----
+            f32x16 s[QW][KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                 for (int tk = 0; tk < C::NKT; ++tk) {
-                    const uint4 kf = *reinterpret_cast<const uint4*>(Ks + kb * 32 * C::KSTR + kfrag + tk * 32);
+                    const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (k0 + kb) * 32 * C::KSTR + kfrag + tk * 32);
 #pragma unroll
                     for (int qb = 0; qb < QW; ++qb)      // first k step takes the inline constant 0 as C: no accumulator clears
                         s[qb][kb] = E::mfma(kf, qf[qb][tk], tk == 0 ? zero16 : s[qb][kb]);
                 }
 
-            uint4 pf[QW][4];
+            uint4 pf[QW][2 * KB];
 #pragma unroll
             for (int qb = 0; qb < QW; ++qb) {
+                const bool first = (t == 0) && (k0 == 0);
+                auto pack_p = [&]() {      // P^T fragments: register octet g of block kb = keys 16g+8hi..+7 of that block
+#pragma unroll
+                    for (int g = 0; g < 2 * KB; ++g) {
+                        const int kb = g >> 1, r0 = (g & 1) * 8;
+                        pf[qb][g].x = E::pack2(s[qb][kb][r0 + 0], s[qb][kb][r0 + 1]);
+                        pf[qb][g].y = E::pack2(s[qb][kb][r0 + 2], s[qb][kb][r0 + 3]);
+                        pf[qb][g].z = E::pack2(s[qb][kb][r0 + 4], s[qb][kb][r0 + 5]);
+                        pf[qb][g].w = E::pack2(s[qb][kb][r0 + 6], s[qb][kb][r0 + 7]);
+                    }
+                };
+                if (OFFS && SPEC) {
+                    // Speculative softmax step: s already holds q.k - m_ref (deferred max, folded into the MFMA), so
+                    // exponentiate and pack straight away; the packed 16-bit P patterns are non-negative, hence ordered
+                    // like integers / like fp16 patterns, and ONE packed 3-input max per two registers finds the largest
+                    // P of the block (inf / NaN patterns included).  Only when some P exceeds 2^OFFS_THR (or on the
+                    // first / ragged block) is the block redone on the exact path below.  Saves the 32-value fp32 max
+                    // tree and the cross-half-wave exchange on every other block.
+                    bool redo = first || ragged;
+                    if (!redo) {
+#pragma unroll
+                        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) s[qb][kb][r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
+                        pack_p();
+                        uint32_t m = pk_max3_f16(pf[qb][0].x, pf[qb][0].y, pf[qb][0].z);
+                        m = pk_max3_f16(m, pf[qb][0].w, pf[qb][1].x);
+                        m = pk_max3_f16(m, pf[qb][1].y, pf[qb][1].z);
+#pragma unroll
+                        for (int g = 2; g < 2 * KB; g += 2) {
+                            m = pk_max3_f16(m, pf[qb][g - 1].w, pf[qb][g].x);
+                            m = pk_max3_f16(m, pf[qb][g].y, pf[qb][g].z);
+                            m = pk_max3_f16(m, pf[qb][g].w, pf[qb][g + 1].x);
+                            m = pk_max3_f16(m, pf[qb][g + 1].y, pf[qb][g + 1].z);
+                        }
+                        m = pk_max3_f16(m, pf[qb][2 * KB - 1].w, pf[qb][2 * KB - 1].w);
+                        const uint32_t top = max(m & 0xffffu, m >> 16);
+                        redo = __any(top > (uint32_t)E::fromf(256.0f));          // 2^OFFS_THR
+                        if (redo) {          // rare: recompute this block's scores (K fragments are still in LDS)
+#pragma unroll
+                            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                                for (int tk = 0; tk < C::NKT; ++tk) {
+                                    const uint4 kf = *reinterpret_cast<const uint4*>(Ks + (k0 + kb) * 32 * C::KSTR + kfrag + tk * 32);
+                                    s[qb][kb] = E::mfma(kf, qf[qb][tk], tk == 0 ? zero16 : s[qb][kb]);
+                                }
+                        }
+                    }
+                    if (!redo) continue;
+                }
                 if (ragged) {     // keys >= L of the last tile contribute nothing
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int key = t * KT + kb * 32 + 8 * hi + (r & 7) + 16 * (r >> 3);
+                            const int key = t * KT + (k0 + kb) * 32 + 8 * hi + (r & 7) + 16 * (r >> 3);
                             if (key >= L) s[qb][kb][r] = -INFINITY;
                         }
                 }
                 // ---- online softmax (base 2; Q carries the scale) ----
                 float mx = s[qb][0][0];
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][kb][r]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 if (OFFS) {
-                    // s already holds q.k - m_ref.  Raise m_ref only on the first tile or past the threshold.
-                    if (t == 0 || __any(mx > OFFS_THR)) {
-                        const float want = m_run[qb] + ((t == 0) ? mx : fmaxf(mx, 0.f));
+                    // s already holds q.k - m_ref.  Raise m_ref only on the first block or past the threshold.
+                    if (first || __any(mx > OFFS_THR)) {
+                        const float want = m_run[qb] + (first ? mx : fmaxf(mx, 0.f));
                         const float nref = E::tof(E::fromf(want));          // what the 16-bit Q slot can carry
                         const float delta = nref - m_run[qb];
-                        if (t != 0) {       // on the first tile O is still 0 (and delta may be hugely negative: 2^-delta = inf)
+                        if (!first) {       // on the first block O is still 0 (and delta may be hugely negative: 2^-delta = inf)
                             const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
                             for (int dt = 0; dt < C::NDT; ++dt)
@@ -240,14 +308,14 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                                 for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
                         }
 #pragma unroll
-                        for (int kb = 0; kb < 2; ++kb)
+                        for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) s[qb][kb][r] -= delta;
                         m_run[qb] = nref;
                         if (hi == QPAD_HI) qf[qb][QPAD_T].x = (qf[qb][QPAD_T].x & 0xffff0000u) | (uint32_t)E::fromf(-nref);
                     }
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) s[qb][kb][r] = __builtin_amdgcn_exp2f(s[qb][kb][r]);
                 } else {
@@ -264,7 +332,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                     }
                     float psum = 0.f;
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float pe = __builtin_amdgcn_exp2f(s[qb][kb][r] - m_new);
@@ -273,25 +341,18 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                         }
                     if (!LSUM_MFMA) l_run[qb] += psum;
                 }
-                // ---- P^T fragments: register octet g of block kb = keys 16g+8hi..+7 of that block ----
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int kb = g >> 1, r0 = (g & 1) * 8;
-                    pf[qb][g].x = E::pack2(s[qb][kb][r0 + 0], s[qb][kb][r0 + 1]);
-                    pf[qb][g].y = E::pack2(s[qb][kb][r0 + 2], s[qb][kb][r0 + 3]);
-                    pf[qb][g].z = E::pack2(s[qb][kb][r0 + 4], s[qb][kb][r0 + 5]);
-                    pf[qb][g].w = E::pack2(s[qb][kb][r0 + 6], s[qb][kb][r0 + 7]);
-                }
+                pack_p();
             }
             // ---- O^T += V^T P^T: every V^T fragment is read once and used for all QW query blocks ----
 #pragma unroll
             for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + g * 32);
+                for (int g = 0; g < 2 * KB; ++g) {
+                    const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + (2 * k0 + g) * 32);
 #pragma unroll
                     for (int qb = 0; qb < QW; ++qb) o[qb][dt] = E::mfma(vf, pf[qb][g], o[qb][dt]);
                 }
+            }
             if (t + 1 < ntiles) store_tile((t + 1) & 1);
             __syncthreads();
         }
@@ -332,12 +393,12 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     }
 }
 
-template <bool F16, int D, int QW, int MINW>
+template <bool F16, int D, int QW, int MINW, int KB = 2, bool SPEC = false>
 int launch_attn(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
     constexpr int lds = 2 * C::BUF;
     static bool attr_set = false;
-    auto kern = attn_kernel<F16, D, QW, MINW>;
+    auto kern = attn_kernel<F16, D, QW, MINW, KB, SPEC>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -351,7 +412,11 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-int g_attn_qw40 = 1;   // query blocks per wave for head dim 40 (tuning knob, imd_set_tuning(0, v)); 1 measured >= 2
+// head-dim-40 kernel variant (tuning knob 0, imd_set_tuning(0, v)); all variants give the same result up to fp32 order:
+//   2 (default): 2 query blocks per wave, 32-key softmax blocks, speculative exp (measured +8 % over 3)
+//   4: 1 query block per wave, 32-key blocks, speculative exp      3: 1 query block, 64-key blocks, exact max every block
+//   1: as 3 with speculative exp
+int g_attn_qw40 = 2;
 
 int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }
@@ -370,8 +435,10 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (p.D) {
         case 40:
-            if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2>(p, s) : launch_attn<false, 40, 2, 2>(p, s);
-            return h ? launch_attn<true, 40, 1, 2>(p, s) : launch_attn<false, 40, 1, 2>(p, s);
+            if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true>(p, s) : launch_attn<false, 40, 2, 2, 1, true>(p, s);
+            if (g_attn_qw40 == 3) return h ? launch_attn<true, 40, 1, 3, 2, false>(p, s) : launch_attn<false, 40, 1, 3, 2, false>(p, s);
+            if (g_attn_qw40 == 4) return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
+            return h ? launch_attn<true, 40, 1, 3, 2, true>(p, s) : launch_attn<false, 40, 1, 3, 2, true>(p, s);
         case 64: return h ? launch_attn<true, 64, 1, 2>(p, s) : launch_attn<false, 64, 1, 2>(p, s);
         case 80: return h ? launch_attn<true, 80, 1, 2>(p, s) : launch_attn<false, 80, 1, 2>(p, s);
         case 160: return h ? launch_attn<true, 160, 1, 1>(p, s) : launch_attn<false, 160, 1, 1>(p, s);

@@ -43,7 +43,7 @@ template <int BM, int BN, int BK, int WAVES_M> struct TileCfg {
 
 // VAR: main-loop schedule.  0 = fragments read per 16-deep k step; 1 = all fragments of the tile read up front
 //      (one LDS latency per tile instead of four) -- needs 64 more VGPRs, only for the 128x128 tile.
-template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int VAR>
+template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int VAR, int DEPTH>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
     using E = El<F16>;
     using T = TileCfg<BM, BN, BK, WAVES_M>;
@@ -117,9 +117,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
         w_off[i] = (n < p.N) ? (uint32_t)(((size_t)n * p.K + kc * 8) * 2) : OOB;
     }
 
-    // two register staging sets: tile t+1 and t+2 are in flight while tile t is multiplied (global / L2
-    // latency under load is ~2 K-tile times; a single set stalls every iteration on vmcnt)
-    uint4 a_r0[A_VECS], w_r0[W_VECS], a_r1[A_VECS], w_r1[W_VECS];
+    // DEPTH register staging sets: tiles t+1 .. t+DEPTH are in flight while tile t is multiplied (global / L2
+    // latency under load is ~2 K-tile times of the big tiles and many more of the small ones; a single set stalls
+    // every iteration on vmcnt)
+    uint4 a_r[DEPTH][A_VECS], w_r[DEPTH][W_VECS];
 
     // K-tile order.  Default: k = tile * BK (tap-major, channels inner).  "tap-inner" (3x3 convs with Cin % BK == 0):
     // tile j -> channel chunk j / 9, tap j % 9, so CONSECUTIVE tiles are neighbouring taps of the same channels and
@@ -218,27 +219,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     };
 
     // Software pipeline (tiles past the K range read as zero, so the steady state needs no guards):
-    // LDS buffer b holds tile t (being multiplied); register set (t+1)&1 holds tile t+1 (landed one iteration
-    // ago) and is written to the other LDS buffer after the MFMAs; register set t&1 is refilled with tile t+2.
-    load_tile(kt_begin, a_r0, w_r0);
-    load_tile(kt_begin + 1, a_r1, w_r1);
-    store_a(0, a_r0);
-    store_w(0, w_r0);
+    // LDS buffer t&1 holds tile t (being multiplied); register set (t+i) % DEPTH holds tile t+i, i = 1..DEPTH-1;
+    // iteration t refills set t % DEPTH with tile t+DEPTH, multiplies, then parks tile t+1 in the other LDS buffer.
+    // Unrolled by DEPTH (even) so that every set / buffer index is a compile-time constant.
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) load_tile(kt_begin + i, a_r[i], w_r[i]);
+    store_a(0, a_r[0]);
+    store_w(0, w_r[0]);
     __syncthreads();
 
-    for (int kt = kt_begin; kt < kt_end; kt += 2) {
-        load_tile(kt + 2, a_r0, w_r0);
-        mma_tile(0);
-        store_a(1, a_r1);
-        store_w(1, w_r1);
-        __syncthreads();
-        if (kt + 1 < kt_end) {
-            load_tile(kt + 3, a_r1, w_r1);
-            mma_tile(1);
-            store_a(0, a_r0);
-            store_w(0, w_r0);
+    for (int kt = kt_begin; kt < kt_end; kt += DEPTH) {
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) {
+            if (i == 0 || kt + i < kt_end) {
+                load_tile(kt + i + DEPTH, a_r[i], w_r[i]);
+                mma_tile(i & 1);
+                store_a((i + 1) & 1, a_r[(i + 1) % DEPTH]);
+                store_w((i + 1) & 1, w_r[(i + 1) % DEPTH]);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 
     // ---- epilogue, one wave-row group (EROWS rows of the tile) at a time: accumulators -> LDS (fp32; lane owns
@@ -311,11 +311,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams
     }
 }
 
-template <bool F16, int BM, int BN, int BK, int WM, int WN, int VAR = 0>
+template <bool F16, int BM, int BN, int BK, int WM, int WN, int VAR = 0, int DEPTH = 2>
 int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
+    static_assert(DEPTH == 2 || DEPTH == 4, "pipeline depth");
     constexpr int lds = TileCfg<BM, BN, BK, WM>::LDS;
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN, VAR>;
+    auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN, VAR, DEPTH>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -337,7 +338,9 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 0: *bm = 128; *bn = 128; return 0;
         case 1: *bm = 128; *bn = 64; return 0;
         case 2: *bm = 64; *bn = 64; return 0;
-        case 3: case 4: case 5: *bm = 128; *bn = 128; return 0;
+        case 4: case 5: case 8: *bm = 128; *bn = 128; return 0;
+        case 3: case 7: *bm = 64; *bn = 64; return 0;
+        case 6: *bm = 64; *bn = 320; return 0;
         default: return 1;
     }
 }
@@ -406,8 +409,11 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 0: return h ? launch_cfg<true, 128, 128, 64, 2, 2>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2>(p, s);
         case 1: return h ? launch_cfg<true, 128, 64, 64, 2, 2>(p, s) : launch_cfg<false, 128, 64, 64, 2, 2>(p, s);
         case 2: return h ? launch_cfg<true, 64, 64, 64, 2, 2>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2>(p, s);
-        case 3: return h ? launch_cfg<true, 128, 128, 64, 2, 2, 1>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2, 1>(p, s);   // experimental schedule
+        case 3: return h ? launch_cfg<true, 64, 64, 64, 2, 2, 0, 4>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2, 0, 4>(p, s);       // 4 tiles in flight
         case 4: return h ? launch_cfg<true, 128, 128, 32, 2, 2>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2>(p, s);         // 41 KB LDS: 3 workgroups / CU
+        case 6: return h ? launch_cfg<true, 64, 320, 32, 2, 2>(p, s) : launch_cfg<false, 64, 320, 32, 2, 2>(p, s);               // N % 320 == 0: no idle columns, A read once
+        case 7: return h ? launch_cfg<true, 64, 64, 32, 2, 2, 0, 4>(p, s) : launch_cfg<false, 64, 64, 32, 2, 2, 0, 4>(p, s);       // 20 KB LDS: 8 workgroups / CU
+        case 8: return h ? launch_cfg<true, 128, 128, 32, 2, 2, 0, 4>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2, 0, 4>(p, s);
         case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
             int rc = imd_launch_conv_patch(p, s);
             if (rc || p.split_k <= 1) return rc;

@@ -127,7 +127,9 @@ int imd_device_check(int device);
  * ResnetBlock2D.conv1/conv2/conv_shortcut/time_emb_proj, Down/Upsample2D.conv, Transformer2DModel.proj_in/out,
  * Attention.to_q/to_k/to_v/to_out[0], FeedForward (GEGLU), TimestepEmbedding, ControlNet zero-convs; and
  * RefSAttnProcessor2_0.to_k_ref/to_v_ref (adapter/attention_processor.py:600-601), to_k_ip/to_v_ip (:841-842),
- * the nn.Linear layers of adapter/resampler.py.  cfg: -1 auto, 0: 128x128x64, 1: 128x64x64, 2: 64x64x64, 4: 128x128x32 tiles, 5: 3x3 halo-patch kernel. */
+ * the nn.Linear layers of adapter/resampler.py.  cfg (rows x channels x K-depth of a workgroup tile): -1 auto, 0: 128x128x64, 1: 128x64x64, 2: 64x64x64,
+ * 3: 64x64x64 with 4 K tiles in flight, 4: 128x128x32, 5: 3x3 halo-patch kernel, 6: 64x320x32 (N % 320 == 0: no idle columns),
+ * 7: 64x64x32 / 4 in flight, 8: 128x128x32 / 4 in flight.  Results are identical up to fp32 summation order. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);
 /* suggested number of K slices for tile config `cfg` (1 = do not split) */
@@ -140,7 +142,7 @@ int imd_conv_gemm_auto_split(int M, int N, int K, int cfg);
 int imd_attention(const imd_attn_params* p, void* stream);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
-/* performance knobs (results are identical for every setting).  knob 0: 32-row query blocks per wave for head dim 40 (1|2);
+/* performance knobs (results are identical for every setting).  knob 0: head-dim-40 attention kernel variant (1..4, default 2: two 32-row query blocks per wave, 32-key softmax blocks, speculative exp);
  * knob 1: XCD-aware work mapping of the attention grid (0|1);
  * knob 2: GEMM operand-fetch bits (bit0: tap-inner K order for 3x3 convs, bit1: weight loads bypass the L1). */
 int imd_set_tuning(int knob, int value);

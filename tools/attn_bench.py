@@ -41,10 +41,16 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only-l0", action="store_true")
+    ap.add_argument("--variants", default="", help="comma list of knob-0 values to A/B on the level-0 shape")
+    ap.add_argument("--default-only", action="store_true", help="level-0 shape with the library's default knobs only (PMC passes)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     cases = [(40, 4096, 4096, 4, 2, 1), (40, 4096, 4096, 4, 1, 1), (40, 4096, 4096, 4, 2, 0), (40, 4096, 4096, 4, 1, 0)]
-    if not a.only_l0:
+    if a.variants:
+        cases = [(40, 4096, 4096, 4, int(v), 1) for v in a.variants.split(",")]
+    elif a.default_only:
+        cases = [(40, 4096, 4096, 4, None, 1)]
+    elif not a.only_l0:
         cases += [(80, 1024, 1024, 4, None, 1), (80, 1024, 1024, 4, None, 0), (160, 256, 256, 4, None, 1), (160, 64, 64, 4, None, 1)]
     for rep in range(2):          # interleaved repeats: within-run A/B
         for D, N, M, Bi, qw, xcd in cases:

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pass$i -o a -- python $R/tools/attn_bench.py --only-l0 --iters 2 > $R/$OUT/pass$i.out 2>&1
+  timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pass$i -o a -- python $R/tools/attn_bench.py --default-only --iters 2 > $R/$OUT/pass$i.out 2>&1
 done
 cd $R
 python tools/pmc_summary.py $OUT attn_kernel > $OUT/summary.txt 2>&1
