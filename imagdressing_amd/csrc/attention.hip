@@ -67,7 +67,7 @@ __device__ __forceinline__ uint32_t pk_max3_f16(uint32_t a, uint32_t b, uint32_t
     return d;
 }
 
-template <bool F16, int D, int QW, int MINW, int KB, bool SPEC>
+template <bool F16, int D, int QW, int MINW, int KB, bool SPEC, int SCHED>
 __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     using C = AttnCfg<D>;
     using E = El<F16>;
@@ -226,8 +226,18 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                 }
 
             uint4 pf[QW][2 * KB];
+            // With several query blocks per wave the P.V MFMAs of block qb are issued right after ITS softmax, so that
+            // they execute underneath the VALU work of block qb+1 (V^T fragments are read once, up front).
+            constexpr bool PVSPLIT = QW > 1 && (SCHED & 1);
+            uint4 vfr[PVSPLIT ? C::NDT : 1][PVSPLIT ? 2 * KB : 1];
+            if (PVSPLIT) {
 #pragma unroll
-            for (int qb = 0; qb < QW; ++qb) {
+                for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 2 * KB; ++g)
+                        vfr[dt][g] = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + (2 * k0 + g) * 32);
+            }
+            auto softmax_block = [&](int qb) {
                 const bool first = (t == 0) && (k0 == 0);
                 auto pack_p = [&]() {      // P^T fragments: register octet g of block kb = keys 16g+8hi..+7 of that block
 #pragma unroll
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                                 }
                         }
                     }
-                    if (!redo) continue;
+                    if (!redo) return;
                 }
                 if (ragged) {     // keys >= L of the last tile contribute nothing
 #pragma unroll
@@ -342,16 +352,28 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                     if (!LSUM_MFMA) l_run[qb] += psum;
                 }
                 pack_p();
+            };
+#pragma unroll
+            for (int qb = 0; qb < QW; ++qb) {
+                softmax_block(qb);
+                if (PVSPLIT) {
+#pragma unroll
+                    for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+                        for (int g = 0; g < 2 * KB; ++g) o[qb][dt] = E::mfma(vfr[dt][g], pf[qb][g], o[qb][dt]);
+                        }
             }
             // ---- O^T += V^T P^T: every V^T fragment is read once and used for all QW query blocks ----
+            if (!PVSPLIT) {
 #pragma unroll
-            for (int dt = 0; dt < C::NDT; ++dt)
+                for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
-                for (int g = 0; g < 2 * KB; ++g) {
-                    const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + (2 * k0 + g) * 32);
+                    for (int g = 0; g < 2 * KB; ++g) {
+                        const uint4 vf = *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + (2 * k0 + g) * 32);
 #pragma unroll
-                    for (int qb = 0; qb < QW; ++qb) o[qb][dt] = E::mfma(vf, pf[qb][g], o[qb][dt]);
-                }
+                        for (int qb = 0; qb < QW; ++qb) o[qb][dt] = E::mfma(vf, pf[qb][g], o[qb][dt]);
+                    }
+            }
             }
             if (t + 1 < ntiles) store_tile((t + 1) & 1);
             __syncthreads();
@@ -393,12 +415,12 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     }
 }
 
-template <bool F16, int D, int QW, int MINW, int KB = 2, bool SPEC = false>
+template <bool F16, int D, int QW, int MINW, int KB = 2, bool SPEC = false, int SCHED = 0>
 int launch_attn(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
     constexpr int lds = 2 * C::BUF;
     static bool attr_set = false;
-    auto kern = attn_kernel<F16, D, QW, MINW, KB, SPEC>;
+    auto kern = attn_kernel<F16, D, QW, MINW, KB, SPEC, SCHED>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -435,10 +457,11 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (p.D) {
         case 40:
-            if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true>(p, s) : launch_attn<false, 40, 2, 2, 1, true>(p, s);
+            if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 1>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 1>(p, s);
             if (g_attn_qw40 == 3) return h ? launch_attn<true, 40, 1, 3, 2, false>(p, s) : launch_attn<false, 40, 1, 3, 2, false>(p, s);
             if (g_attn_qw40 == 4) return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
-            return h ? launch_attn<true, 40, 1, 3, 2, true>(p, s) : launch_attn<false, 40, 1, 3, 2, true>(p, s);
+            if (g_attn_qw40 == 1 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 0>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 0>(p, s);
+            return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
         case 64: return h ? launch_attn<true, 64, 1, 2>(p, s) : launch_attn<false, 64, 1, 2>(p, s);
         case 80: return h ? launch_attn<true, 80, 1, 2>(p, s) : launch_attn<false, 80, 1, 2>(p, s);
         case 160: return h ? launch_attn<true, 160, 1, 1>(p, s) : launch_attn<false, 160, 1, 1>(p, s);
