@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     const int wn0 = (wave % WAVES_N) * (TN * 32);
 
     const int n_tiles = (p.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / n_tiles;
-    const int tile_n = blockIdx.x - tile_m * n_tiles;
+    int tile_m, tile_n;
+    xcd_tile_order(p.flags, (p.M + BM - 1) / BM, n_tiles, tile_m, tile_n);
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -347,7 +347,17 @@ int tile_dims(int cfg, int* bm, int* bn) {
 
 }  // namespace
 
-int g_gemm_flags = 3;   // tuning knob 2: bit0 tap-inner K order for 3x3 convs, bit1 weight loads bypass L1
+int g_gemm_flags = 7;   // tuning knob 2: bit0 tap-inner K order for 3x3 convs, bit1 weight loads bypass L1, bit2 XCD-aware tile order
+
+// tile-order flag (see xcd_tile_order): fabric bytes if every XCD owns whole row tiles (activations once, weights x8) vs
+// whole channel tiles (weights once, activations x min(8, channel tiles))
+int imd_gemm_pick_order(const ConvGemmParams& p, int n_tiles) {
+    const double a_bytes = (double)p.x_bytes, w_bytes = (double)p.w_bytes / (p.split_k > 1 ? p.split_k : 1);
+    const double a_split = a_bytes / (p.split_k > 1 && p.taps == 1 ? p.split_k : 1);
+    const double cost_m = a_split + 8.0 * w_bytes;
+    const double cost_n = (n_tiles < 8 ? n_tiles : 8) * a_split + w_bytes;
+    return cost_m <= cost_n ? 4 : 8;
+}
 
 int imd_conv_gemm_choose_cfg(int M, int N) {
     const long b128 = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -396,6 +406,11 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         const bool big_map = p.taps == 9 && p.Wout >= 32;
         if ((g_gemm_flags & 1) && big_map && (p.Cin % bk) == 0) p.flags |= 1;
         if ((g_gemm_flags & 2) && big_map) p.flags |= 2;
+    }
+    if (g_gemm_flags & 4) {
+        int bm = 128, bn = 128;
+        tile_dims(cfg, &bm, &bn);
+        p.flags |= imd_gemm_pick_order(p, (p.N + bn - 1) / bn);
     }
     if (p.split_k > 1) {
         if (p.mode == OUT_HEADS || p.act == ACT_GEGLU) return imd_set_error("conv_gemm: split-K supports row-major epilogues only");

@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     const int H = p.Hin, W = p.Win;
     const int tiles_x = W / TW, tiles_y = H / TH;
     const int n_tiles = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x;
-    const int tile_n = bid % n_tiles; bid /= n_tiles;
+    int bid, tile_n;
+    xcd_tile_order(p.flags, (int)(gridDim.x / n_tiles), n_tiles, bid, tile_n);      // bid = pixel-tile index
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;

@@ -21,6 +21,25 @@ __device__ __forceinline__ uint4 buf_load16_nl1(const __amdgpu_buffer_rsrc_t& rs
 
 constexpr uint32_t OOB = 0xffffffffu;   // any offset past num_records reads as zero
 
+// XCD-aware tile order.  Hardware workgroup x of a grid row runs on XCD (x + const) % 8, each XCD with a private 4 MiB L2.
+// With the plain order the (row tile, channel tile) pairs that share an operand tile are sprayed over all eight L2s,
+// so every activation tile is pulled through the fabric once per channel tile (and every weight tile once per row
+// tile).  Remap x so that each XCD owns a CONTIGUOUS range of the tile list, ordered
+//   flags & 4: row-tile major    -> all channel tiles of a row tile share one L2 (activations fetched once; the right
+//                                   choice when the activation operand is the big one: the 64x64 / 32x32 levels)
+//   flags & 8: channel-tile major -> all row tiles of a channel tile share one L2 (weights fetched once: the 8x8 / 16x16
+//                                   levels, where K = 11520..23040 weight rows dominate)
+// The launcher picks the cheaper of the two from the operand sizes (imd_gemm_pick_order).
+__device__ __forceinline__ void xcd_tile_order(int flags, int m_tiles, int n_tiles, int& tile_m, int& tile_n) {
+    unsigned w = blockIdx.x;
+    if (flags & 12) {
+        const unsigned gx = gridDim.x, k = w & 7u, slot = w >> 3, q8 = gx >> 3, r8 = gx & 7u;
+        w = (k < r8 ? k * (q8 + 1) : r8 * (q8 + 1) + (k - r8) * q8) + slot;       // bijective also when gx % 8 != 0
+    }
+    if (flags & 8) { tile_n = (int)(w / (unsigned)m_tiles); tile_m = (int)(w - (unsigned)tile_n * m_tiles); }
+    else { tile_m = (int)(w / (unsigned)n_tiles); tile_n = (int)(w - (unsigned)tile_m * n_tiles); }
+}
+
 // ------------------------------------------------------------------------------------------
 // shared epilogue on 8 consecutive channels [n, n+8) of row m (nv = number of valid channels: 4 or 8)
 // ------------------------------------------------------------------------------------------
