@@ -347,7 +347,8 @@ int tile_dims(int cfg, int* bm, int* bn) {
 
 }  // namespace
 
-int g_gemm_flags = 7;   // tuning knob 2: bit0 tap-inner K order for 3x3 convs, bit1 weight loads bypass L1, bit2 XCD-aware tile order
+int g_gemm_flags = 23;   // tuning knob 2: bit0 tap-inner K order for 3x3 convs, bit1 weight loads bypass L1, bit2 XCD-aware tile order,
+                         // bit4 grouped (8 row tiles) order inside an XCD's range
 
 // tile-order flag (see xcd_tile_order): fabric bytes if every XCD owns whole row tiles (activations once, weights x8) vs
 // whole channel tiles (weights once, activations x min(8, channel tiles))
@@ -411,6 +412,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         int bm = 128, bn = 128;
         tile_dims(cfg, &bm, &bn);
         p.flags |= imd_gemm_pick_order(p, (p.N + bn - 1) / bn);
+        p.flags |= g_gemm_flags & 16;
     }
     if (p.split_k > 1) {
         if (p.mode == OUT_HEADS || p.act == ACT_GEGLU) return imd_set_error("conv_gemm: split-K supports row-major epilogues only");

@@ -37,6 +37,17 @@ __device__ __forceinline__ void xcd_tile_order(int flags, int m_tiles, int n_til
         w = (k < r8 ? k * (q8 + 1) : r8 * (q8 + 1) + (k - r8) * q8) + slot;       // bijective also when gx % 8 != 0
     }
     if (flags & 8) { tile_n = (int)(w / (unsigned)m_tiles); tile_m = (int)(w - (unsigned)tile_n * m_tiles); }
+    else if ((flags & 4) && (flags & 16)) {
+        // grouped order inside the XCD's range: 8 row tiles x all channel tiles, row tile fastest -- the workgroups that
+        // are resident together then share 8 activation tiles and a handful of weight tiles instead of sweeping the whole
+        // weight matrix once per row tile (which overflows the 4 MiB L2 when N*K*2 does: the GEGLU / qkv projections)
+        constexpr unsigned GM = 8;
+        const unsigned per_group = GM * (unsigned)n_tiles;
+        const unsigned g = w / per_group, r = w - g * per_group;
+        const unsigned rows = min(GM, (unsigned)m_tiles - g * GM);
+        tile_n = (int)(r / rows);
+        tile_m = (int)(g * GM + (r - (unsigned)tile_n * rows));
+    }
     else { tile_m = (int)(w / (unsigned)n_tiles); tile_n = (int)(w - (unsigned)tile_m * n_tiles); }
 }
 

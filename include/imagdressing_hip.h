@@ -145,7 +145,8 @@ int imd_attn_padded_dims(int D, int* dpk, int* dpv);
 /* performance knobs (results are identical for every setting).  knob 0: head-dim-40 attention kernel variant (1..4, default 2: two 32-row query blocks per wave, 32-key softmax blocks, speculative exp);
  * knob 1: XCD-aware work mapping of the attention grid (0|1);
  * knob 2: GEMM operand-fetch bits (bit0: tap-inner K order for 3x3 convs, bit1: weight loads bypass the L1,
- * bit2: XCD-aware tile order -- each XCD's L2 owns whole row tiles or whole channel tiles, whichever moves fewer bytes). */
+ * bit2: XCD-aware tile order -- each XCD's L2 owns whole row tiles or whole channel tiles, whichever moves fewer bytes;
+ * bit4: row tiles visited in groups of 8 inside an XCD's range). */
 int imd_set_tuning(int knob, int value);
 
 /* GroupNorm (+SiLU) over NHWC: diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out. */
