@@ -31,7 +31,7 @@ class ConvGemmParams(C.Structure):
         ("mode", C.c_int), ("hC", C.c_int), ("hH", C.c_int), ("hD", C.c_int),
         ("hd", HeadsDest * 3), ("dtype", C.c_int), ("split_k", C.c_int), ("splitk_ws", C.c_void_p),
         ("x_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("flags", C.c_int),
-        ("gn_a", C.c_void_p), ("gn_b", C.c_void_p), ("gn_silu", C.c_int),
+        ("gn_a", C.c_void_p), ("gn_b", C.c_void_p), ("gn_silu", C.c_int), ("pad_br_only", C.c_int),
     ]
 
 
@@ -88,6 +88,7 @@ SYMBOLS = {
     "imd_conv_patch_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_groupnorm_workspace_floats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "imd_layernorm": (C.c_int, [C.POINTER(LayerNormParams), C.c_void_p]),
+    "imd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "imd_ddim_cfg_step": (C.c_int, [C.POINTER(DdimParams), C.c_void_p]),
     "imd_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imd_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float, C.c_int, C.c_void_p]),

@@ -100,6 +100,11 @@ int imd_layernorm(const imd_layernorm_params* p, void* stream) {
     return imd_launch_layernorm(*p, (hipStream_t)stream);
 }
 
+int imd_softmax_rows(const float* s, int s_ld, uint16_t* p, int p_ld, int rows, int cols, int dtype, void* stream) {
+    IMD_REQUIRE(s && p, "softmax_rows: null pointer");
+    return imd_launch_softmax_rows(s, s_ld, p, p_ld, rows, cols, dtype, (hipStream_t)stream);
+}
+
 int imd_ddim_cfg_step(const imd_ddim_params* p, void* stream) {
     IMD_REQUIRE(p && p->z && p->eps, "ddim_cfg_step: null pointer");
     IMD_REQUIRE(p->sqrt_a_t > 0.f, "ddim_cfg_step: sqrt(alpha_t) must be positive");

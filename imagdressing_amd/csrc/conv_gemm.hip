@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
 
     // ---- per-row gather setup (rows are fixed for the whole K loop) ----
     const int HWo = p.Hout * p.Wout;
-    const int pad = (p.taps == 9) ? 1 : 0;
+    const int pad = (p.taps == 9 && !p.pad_br_only) ? 1 : 0;
     const int Hl = p.ups ? p.Hin * 2 : p.Hin;   // logical (post-upsample) input size
     const int Wl = p.ups ? p.Win * 2 : p.Win;
     int a_base[A_VECS];    // pixel index of (b, 0, 0), or -1 when the row is out of range

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 }  // namespace
 
 bool imd_conv_patch_supported(const ConvGemmParams& p) {
-    return p.taps == 9 && p.stride == 1 && !p.ups && p.Hin == p.Hout && p.Win == p.Wout && (p.Hin % TH) == 0 &&
+    return p.taps == 9 && p.stride == 1 && !p.ups && !p.pad_br_only && p.Hin == p.Hout && p.Win == p.Wout && (p.Hin % TH) == 0 &&
            (p.Win % TW) == 0 && (p.Cin % CK) == 0 && p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU;
 }
 

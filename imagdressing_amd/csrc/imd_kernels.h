@@ -35,6 +35,7 @@ int imd_attn_dpv(int D);
 int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s);
 int imd_launch_groupnorm_coeffs(const GroupNormParams& p, float* ca, float* cb, hipStream_t s);
 int imd_launch_layernorm(const LayerNormParams& p, hipStream_t s);
+int imd_launch_softmax_rows(const float* s_in, int s_ld, bf16_t* p_out, int p_ld, int rows, int cols, int dtype, hipStream_t s);
 int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s);
 int imd_launch_timestep_embedding(const float* t, float* out, int B, int dim, hipStream_t s);
 int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, int dtype, hipStream_t s);

@@ -223,6 +223,55 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coeffs_kernel(const GroupNormPa
     }
 }
 
+// Normalise with precomputed per-(batch, channel) coefficients (gn_coeffs_kernel): used for very large feature maps
+// (the VAE's 256x256 / 512x512 levels), where folding thousands of per-chunk partials in every apply block would cost
+// more than the normalisation itself.
+template <bool F16>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_coeffs_kernel(const GroupNormParams p, const float* __restrict__ ca, const float* __restrict__ cb) {
+    const int vpp = p.C / 8;
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int ppc = gn_pix_per_chunk(p.B, p.HW, p.C);
+    const int pix0 = chunk * ppc;
+    const int pix1 = min(p.HW, pix0 + ppc);
+    const int cols = min(vpp, GN_THREADS);
+    const int plan = GN_THREADS / cols;
+    const int my_col = tid % cols, my_pl = tid / cols;
+    if (my_pl >= plan) return;
+    for (int cbase = 0; cbase < vpp; cbase += cols) {
+        const int vec = cbase + my_col;
+        if (vec >= vpp) continue;
+        const int c0 = vec * 8;
+        float a[8], sh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a[e] = ca[(size_t)b * p.C + c0 + e]; sh[e] = cb[(size_t)b * p.C + c0 + e]; }
+        const bf16_t* xb = p.x + (size_t)b * p.HW * p.x_ld + c0;
+        bf16_t* yb = p.y + (size_t)b * p.HW * p.y_ld + c0;
+        for (int pix = pix0 + my_pl; pix < pix1; pix += 4 * plan) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = pix + u * plan;
+                v[u] = (px < pix1) ? *reinterpret_cast<const uint4*>(xb + (size_t)px * p.x_ld) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = pix + u * plan;
+                if (px >= pix1) continue;
+                float f[8];
+                unpack8<F16>(v[u], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = f[e] * a[e] + sh[e];
+                    if (p.silu) y = silu_f(y);
+                    f[e] = y;
+                }
+                *reinterpret_cast<uint4*>(yb + (size_t)px * p.y_ld) = pack8<F16>(f);
+            }
+        }
+    }
+}
+
 // One wave per row; C <= 8 * 64 * LN_MAXV.
 constexpr int LN_MAXV = 4;
 template <bool F16>
@@ -270,16 +319,79 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LayerNormParams p)
     }
 }
 
+// Row softmax, fp32 -> 16 bit: one workgroup per row; the row lives in registers (NV values per thread, loops fully
+// unrolled so that the array is never indexed dynamically).
+template <bool F16, int NV>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s_in, int s_ld, bf16_t* __restrict__ p_out, int p_ld, int cols) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = s_in + (size_t)blockIdx.x * s_ld;
+    bf16_t* out = p_out + (size_t)blockIdx.x * p_ld;
+    float v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid + i * 256;
+        v[i] = c < cols ? row[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = __builtin_amdgcn_exp2f((v[i] - mx) * LOG2E);       // exp2(-inf) = 0 for the columns past the row
+        sum += v[i];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid + i * 256;
+        if (c < cols) out[c] = El<F16>::fromf(v[i] * inv);
+    }
+}
+
+template <bool F16>
+void launch_softmax(const float* s_in, int s_ld, bf16_t* p_out, int p_ld, int rows, int cols, hipStream_t s) {
+    const int nv = (cols + 255) / 256;
+    if (nv <= 4) hipLaunchKernelGGL((softmax_rows_kernel<F16, 4>), dim3(rows), dim3(256), 0, s, s_in, s_ld, p_out, p_ld, cols);
+    else if (nv <= 16) hipLaunchKernelGGL((softmax_rows_kernel<F16, 16>), dim3(rows), dim3(256), 0, s, s_in, s_ld, p_out, p_ld, cols);
+    else if (nv <= 32) hipLaunchKernelGGL((softmax_rows_kernel<F16, 32>), dim3(rows), dim3(256), 0, s, s_in, s_ld, p_out, p_ld, cols);
+    else hipLaunchKernelGGL((softmax_rows_kernel<F16, 64>), dim3(rows), dim3(256), 0, s, s_in, s_ld, p_out, p_ld, cols);
+}
+
 }  // namespace
 
+int imd_launch_softmax_rows(const float* s_in, int s_ld, bf16_t* p_out, int p_ld, int rows, int cols, int dtype, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return imd_set_error("softmax_rows: empty matrix");
+    if (cols > 256 * 64) return imd_set_error("softmax_rows: at most %d columns (got %d)", 256 * 64, cols);
+    if (s_ld < cols || p_ld < cols) return imd_set_error("softmax_rows: row strides shorter than the row");
+    if (dtype != IMD_DTYPE_BF16 && dtype != IMD_DTYPE_F16) return imd_set_error("softmax_rows: unknown dtype %d", dtype);
+    if (dtype == IMD_DTYPE_F16) launch_softmax<true>(s_in, s_ld, p_out, p_ld, rows, cols, s);
+    else launch_softmax<false>(s_in, s_ld, p_out, p_ld, rows, cols, s);
+    return imd_check_launch("softmax_rows");
+}
+
+constexpr int GN_TWO_LEVEL_CHUNKS = 256;   // more per-chunk partials than this: fold once (coefficients), then apply
+
 int imd_groupnorm_workspace_floats(int B, int HW, int C, int G) {
-    return B * gn_chunks(B, HW, C) * G * 2;
+    return B * gn_chunks(B, HW, C) * G * 2 + 2 * B * C;
 }
 
 static int gn_validate(const GroupNormParams& p) {
     if (p.B <= 0 || p.HW <= 0 || p.C <= 0) return imd_set_error("groupnorm: empty tensor");
     if (p.C % 8 || p.C % p.G || p.G > 64) return imd_set_error("groupnorm: C (%d) must be a multiple of 8 and of G (%d <= 64)", p.C, p.G);
-    if ((p.C / p.G) < 8) return imd_set_error("groupnorm: channels per group (%d) must be >= 8", p.C / p.G);
+    if ((p.C / p.G) < 4 || ((p.C / p.G) < 8 && (8 % (p.C / p.G)) != 0))
+        return imd_set_error("groupnorm: channels per group (%d) must be 4 or >= 8 (an 8-channel vector may span two groups)", p.C / p.G);
     if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("groupnorm: pixel strides must be multiples of 8");
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("groupnorm: unknown dtype %d", p.dtype);
     return 0;
@@ -303,6 +415,15 @@ int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
     const int chunks = gn_chunks(p.B, p.HW, p.C);
     dim3 grid(chunks, p.B);
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if (chunks > GN_TWO_LEVEL_CHUNKS) {
+        float* ca = p.partial + (size_t)p.B * chunks * p.G * 2;
+        float* cb = ca + (size_t)p.B * p.C;
+        int rc = imd_launch_groupnorm_coeffs(p, ca, cb, s);
+        if (rc) return rc;
+        if (h) hipLaunchKernelGGL(gn_apply_coeffs_kernel<true>, grid, dim3(GN_THREADS), 0, s, p, ca, cb);
+        else hipLaunchKernelGGL(gn_apply_coeffs_kernel<false>, grid, dim3(GN_THREADS), 0, s, p, ca, cb);
+        return imd_check_launch("groupnorm apply (coefficients)");
+    }
     if (h) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, p);
     else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, p);
     int rc = imd_check_launch("groupnorm stats");

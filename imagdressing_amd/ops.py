@@ -90,7 +90,7 @@ def pad64(n: int) -> int:
 # ---------------------------------------------------------------------------------------------
 # Per-shape tile / split-K choices measured on MI355X by tools/gemm_tune.py (like a BLAS tuning file); shapes that
 # are not listed fall back to the library heuristic.  Key: "M,N,K,taps,stride,ups".
-PATCH_CONV = False         # route eligible 3x3 stride-1 convs (W >= PATCH_MIN_W) to the halo-patch kernel (cfg 5)
+PATCH_CONV = True          # untabulated 3x3 stride-1 convs on maps >= PATCH_MIN_W wide use the halo-patch kernel (cfg 5)
 PATCH_MIN_W = 32
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 _GEMM_TABLE = None
@@ -118,7 +118,7 @@ def conv_gemm(
     rowvec_off: int = 0, res: Optional[torch.Tensor] = None, res_ld: Optional[int] = None, out_scale: float = 1.0,
     act: int = ACT_NONE, out_f32: bool = False,
     heads: Optional[dict] = None, cfg: int = -1, split_k: int = 0,
-    gn: Optional[tuple] = None,
+    gn: Optional[tuple] = None, pad_br_only: bool = False,
 ) -> Optional[torch.Tensor]:
     """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
 
@@ -149,6 +149,7 @@ def conv_gemm(
     p.res = _opt(res, dt, "res")
     p.res_ld = (N if res_ld is None else res_ld)
     p.out_scale = out_scale
+    p.pad_br_only = int(pad_br_only)
     p.act = act
     p.out_f32 = int(out_f32)
     if heads is not None:
@@ -175,8 +176,6 @@ def conv_gemm(
     if GEMM_TRACE is not None:
         GEMM_TRACE.append(dict(M=M, N=N, K=K, Cin=Cin, taps=taps, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride,
                                ups=int(ups), splittable=splittable, dtype=str(dt)))
-    if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and not ups and Wout >= PATCH_MIN_W and lib.imd_conv_patch_supported(C.byref(p)):
-        cfg = 5
     if cfg == -1 and split_k == 0:
         ent = _gemm_table().get(f"{M},{N},{K},{taps},{stride},{int(ups)}")
         if ent is not None:
@@ -184,6 +183,11 @@ def conv_gemm(
                 cfg, split_k = ent["cfg"], ent["split"]
             else:
                 cfg, split_k = ent["cfg_nosplit"], 1
+    # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
+    # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
+    if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and not ups and Wout >= PATCH_MIN_W and N >= 64 \
+            and lib.imd_conv_patch_supported(C.byref(p)):
+        cfg = 5
     if split_k == 0:        # auto: K slices only where the tile grid cannot fill the chip
         split_k = 1 if not splittable else lib.imd_conv_gemm_auto_split(M, N, K, cfg)
     p.split_k = split_k
@@ -214,8 +218,9 @@ def linear(x2d: torch.Tensor, w: torch.Tensor, bias=None, *, res=None, act=ACT_N
 
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
-                rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0, gn=None) -> torch.Tensor:
-    """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout]."""
+                rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0, gn=None,
+                pad_br_only=False) -> torch.Tensor:
+    """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout].  ``pad_br_only``: F.pad(x, (0, 1, 0, 1)) + conv(padding=0) (VAE encoder)."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
     Hl, Wl = (2 * H, 2 * W) if ups else (H, W)
@@ -223,7 +228,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1
     M = B * Ho * Wo
     out = conv_gemm(x, w, M=M, N=Cout, Cin=Cin, taps=taps, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups,
                     bias=bias, rowvec=rowvec, rowvec_stride=rowvec_stride, rowvec_off=rowvec_off, res=res, out_scale=out_scale, act=act,
-                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn)
+                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn, pad_br_only=pad_br_only)
     return out.view(B, Ho, Wo, -1)
 
 
@@ -298,6 +303,20 @@ def group_norm_coeffs(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5):
     p.eps, p.silu = eps, 0
     L.check(lib.imd_groupnorm_coeffs(C.byref(p), ab[0].data_ptr(), ab[1].data_ptr(), _stream()))
     return ab[0], ab[1]
+
+
+def softmax_rows(s: torch.Tensor, dtype=bf16, out=None) -> torch.Tensor:
+    """Row softmax of an fp32 matrix [rows, cols] -> 16-bit probabilities (cols <= 16384).  ``out`` may have wider rows
+    (only the first ``cols`` columns of each row are written)."""
+    ensure_device(s.device)
+    rows, cols = s.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=dtype, device=s.device)
+    elif out.shape[0] != rows or out.shape[1] < cols:
+        raise L.ImdError(f"softmax_rows: out {tuple(out.shape)} does not hold a [{rows}, {cols}] matrix")
+    L.check(L.load().imd_softmax_rows(_dev(s, torch.float32, "s"), s.stride(0), _dev(out, out.dtype, "out"), out.stride(0),
+                                      rows, cols, _code(out, "out"), _stream()))
+    return out
 
 
 def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, out=None) -> torch.Tensor:

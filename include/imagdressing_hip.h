@@ -69,6 +69,8 @@ typedef struct imd_conv_gemm_params {
     const float* gn_a;
     const float* gn_b;
     int gn_silu;
+    int pad_br_only;     /* 3x3 taps: 0 = symmetric zero padding 1 (UNet); 1 = padding on the bottom / right edge only, i.e.
+                          * F.pad(x, (0, 1, 0, 1)) + conv(padding = 0): the stride-2 Downsample2D of the VAE encoder */
 } imd_conv_gemm_params;
 
 typedef struct imd_attn_params {
@@ -160,6 +162,10 @@ int imd_conv_patch_supported(const imd_conv_gemm_params* p);
 
 /* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3; adapter/resampler.py:16,43-44,199. */
 int imd_layernorm(const imd_layernorm_params* p, void* stream);
+/* Row softmax, fp32 in -> 16-bit out: p[r][c] = softmax_c(s[r][:cols]) (the upcast softmax of the single-head, d = 512
+ * attention in the VAE mid block -- diffusers AttnProcessor on AutoencoderKL.{encoder,decoder}.mid_block.attentions.0,
+ * reached from IMAGDressing_v1_pipeline.py:457-458,:544).  cols <= 16384, row strides in elements. */
+int imd_softmax_rows(const float* s, int s_ld, uint16_t* p, int p_ld, int rows, int cols, int dtype, void* stream);
 
 /* CFG combine + DDIM step (+ inpaint blend) + next UNet input:
  * IMAGDressing_v1_pipeline.py:483-488,521-532; ..._pipeline_controlnet_inpainting.py:487-500. */

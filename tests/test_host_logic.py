@@ -172,3 +172,20 @@ def test_controlnet_keep():
     assert controlnet_keep(4, 0.0, 1.0) == [1.0] * 4
     assert controlnet_keep(4, 0.5, 1.0) == [0.0, 0.0, 1.0, 1.0]
     assert controlnet_keep(4, 0.0, 0.5) == [1.0, 1.0, 0.0, 0.0]
+
+
+def test_vae_state_dict_layout_matches_diffusers_shape_count():
+    """SD1.5 AutoencoderKL: 248 tensors, 83,653,863 parameters; the engine's shape table == the oracle module's keys"""
+    import math
+
+    from imagdressing_amd.vae import vae_param_shapes
+    from oracle import vae as OV
+    sh = vae_param_shapes()
+    assert len(sh) == 248 and sum(math.prod(v) for v in sh.values()) == 83_653_863
+    o = OV.AutoencoderKL().state_dict()
+    assert set(o) == set(sh) and all(tuple(o[k].shape) == sh[k] for k in sh)
+    small = dict(block_out_channels=(32, 64), layers_per_block=1, norm_num_groups=8)
+    m = OV.AutoencoderKL(small)
+    assert set(m.state_dict()) == set(vae_param_shapes(small))
+    mean, logvar = m.encode_moments(torch.zeros(1, 3, 16, 16))
+    assert mean.shape == logvar.shape == (1, 4, 8, 8) and m.decode(mean).shape == (1, 3, 16, 16)

@@ -320,7 +320,8 @@ def test_attention_extreme_logits(ops, dt):
 # ------------------------------------------------------------------------------------------
 # norms / elementwise
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,HW,Cc", [(2, 256, 320), (1, 100, 640), (2, 64, 960), (1, 70, 1280), (1, 16, 1920), (1, 9, 2560)])
+@pytest.mark.parametrize("B,HW,Cc", [(2, 256, 320), (1, 100, 640), (2, 64, 960), (1, 70, 1280), (1, 16, 1920), (1, 9, 2560),
+                                      (2, 300, 128), (1, 65536, 128), (1, 20000, 256)])      # VAE: 4 channels / group; two-level fold
 @pytest.mark.parametrize("silu", [False, True])
 @DTS
 def test_groupnorm(ops, B, HW, Cc, silu, dt):
