@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=1)
+    ap.add_argument("--decode", action="store_true",
+                    help="also run the HIP VAE decoder (SURVEY 8f rank 1) on the final latents inside the timed region")
     ap.add_argument("--attn-qw", type=int, default=0, help="tuning knob 0 of the library (0 = library default)")
     ap.add_argument("--gemm-flags", type=int, default=-1, help="tuning knob 2 of the library (-1 = library default)")
     return ap.parse_args()
@@ -190,6 +192,9 @@ def main():
     if args.gemm_flags >= 0:
         ops.L.check(ops.L.load().imd_set_tuning(2, args.gemm_flags))
     pipe = build_pipeline(device, dtype, rank)
+    if args.decode:
+        from imagdressing_amd.vae import AutoencoderKL
+        pipe.vae = AutoencoderKL.random_init(seed=5, device=device, dtype=dtype)      # inference_IMAGdressing.py:47-48
     inp = synthetic_inputs(args, device, dtype, rank, world)
     lat_hw = args.res // 8
     N0 = lat_hw * lat_hw
@@ -197,7 +202,7 @@ def main():
     def one_step():
         return pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=args.res, height=args.res,
                     num_inference_steps=args.ddim_steps, guidance_scale=7.5, num_images_per_prompt=args.batch * world,
-                    image_scale=1.0, output_type="latent", shard_over_ranks=world > 1, **inp).images
+                    image_scale=1.0, output_type="pt" if args.decode else "latent", shard_over_ranks=world > 1, **inp).images
 
     def barrier():
         if world > 1:
@@ -246,7 +251,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: SD1.5 {args.dtype}, {args.res}x{args.res}, {args.ddim_steps} DDIM steps, "
                                    f"batch {args.batch}/GPU sharing one garment, garment cross-attn only (RefS + CAttn processors), "
-                                   "random-init weights",
+                                   "random-init weights" + (", VAE decode of the final latents included" if args.decode else ""),
                        "images_per_gpu": args.batch, "global_batch": args.batch * world, "guidance_scale": 7.5,
                        "parallelism": f"dp{world} (image shards; garment features broadcast once per batch)"},
             "outputs_finite": finite,

@@ -201,3 +201,41 @@ def test_pipeline_inpaint_small(dtype):
     # outside the mask the result is exactly the original latents (last step: no re-noising, :494-500)
     keep = (mask == 0).expand(2, 4, -1, -1)
     assert torch.allclose(out.cpu()[keep], img_lat.expand(2, -1, -1, -1)[keep], atol=1e-5)
+
+
+@torch.no_grad()
+def test_build_engines_from_imagdressing_checkpoint(tmp_path):
+    """imagdressing_amd.checkpoint.build_engines (the reference's prepare(), inference_IMAGdressing.py:40-135) from a
+    DeepSpeed-style checkpoint FILE == engines built directly from the same tensors: bit-identical UNet outputs."""
+    from imagdressing_amd import checkpoint as CK
+    from imagdressing_amd import unet as E
+    from imagdressing_amd.adapter.resampler import Resampler
+    dt = torch.float16
+    p = build_pair(SMALL, seed=0, dtype=dt)
+    full = dict(E.SD15_CONFIG, **SMALL)
+    sd_u = E.random_state_dict(E.unet_param_shapes(full), 0)
+    sd_r = E.random_state_dict(E.unet_param_shapes(full), 1)
+    torch.manual_seed(3)
+    rk = dict(dim=64, depth=2, dim_head=16, heads=4, num_queries=16, embedding_dim=96, output_dim=64, ff_mult=2)
+    proj = Resampler(**rk)
+    adapters = torch.nn.ModuleList(p["e_unet"].attn_processors.values())
+    ck = {}
+    ck.update({"ref_unet." + k: v for k, v in sd_r.items()})
+    ck.update({"unet." + k: v for k, v in sd_u.items()})
+    ck.update({"proj." + k: v.detach().cpu() for k, v in proj.state_dict().items()})
+    ck.update({"adapter_modules." + k: v.detach().float().cpu() for k, v in adapters.state_dict().items()})
+    f = tmp_path / "IMAGDressing-v1_small.pt"
+    torch.save({"module": ck}, f)
+    eng = CK.build_engines(sd_u, CK.load_state_dict_file(str(f)), device="cuda", dtype=dt, config=SMALL, resampler_kwargs=rk)
+    assert eng["other_keys"] == [] and eng["unused_unet_keys"] == len(sd_u)
+    x = g(1, 2, 4, 16, 16).cuda(); ehs = g(2, 2, 77, 64, scale=0.5).cuda()
+    refl = g(5, 1, 4, 16, 16); cloth = g(6, 1, 16, 64, scale=0.5)
+    from imagdressing_amd.unet import nchw_to_nhwc8
+    outs = []
+    for unet, ref in ((p["e_unet"], p["e_ref"]), (eng["unet"], eng["ref_unet"])):
+        ref.forward_nhwc(nchw_to_nhwc8(refl.cuda(), dt), 0, cloth.cuda().to(dt).contiguous())
+        sa = {n: pr.cache["hidden_states"] for n, pr in ref.attn_processors.items()}
+        outs.append(unet(x, 301, ehs, cross_attention_kwargs={"sa_hidden_states": sa})[0])
+    assert torch.equal(outs[0], outs[1])
+    clip = g(7, 1, 20, 96, scale=0.5).cuda().to(dt)
+    assert torch.equal(eng["image_proj"](clip), proj.to(device="cuda", dtype=dt)(clip))

@@ -189,3 +189,25 @@ def test_vae_state_dict_layout_matches_diffusers_shape_count():
     assert set(m.state_dict()) == set(vae_param_shapes(small))
     mean, logvar = m.encode_moments(torch.zeros(1, 3, 16, 16))
     assert mean.shape == logvar.shape == (1, 4, 8, 8) and m.decode(mean).shape == (1, 3, 16, 16)
+
+
+def test_imagdressing_checkpoint_split_and_file_roundtrip(tmp_path):
+    """key routing of inference_IMAGdressing.py:99-112 and the DeepSpeed {"module": ...} unwrapping (:97)"""
+    from imagdressing_amd import checkpoint as CK
+    sd = {"ref_unet.conv_in.weight": torch.ones(2), "unet.conv_in.weight": torch.zeros(2), "proj.latents": torch.ones(1, 2, 3),
+          "adapter_modules.0.to_k_ref.weight": torch.ones(3, 3), "adapter_modules.31.to_v_ref.weight": torch.ones(3, 3),
+          "projection_extra": torch.ones(1), "optimizer_state": torch.ones(1)}
+    parts = CK.split_imagdressing_state_dict(sd)
+    assert set(parts["ref_unet"]) == {"conv_in.weight"} and set(parts["unet"]) == {"conv_in.weight"}
+    assert set(parts["proj"]) == {"latents", "projection_extra"}      # the reference's startswith("proj") also swallows this key
+    assert set(parts["adapter_modules"]) == {"0.to_k_ref.weight", "31.to_v_ref.weight"} and set(parts["other"]) == {"optimizer_state"}
+    f = tmp_path / "ck.pt"
+    torch.save({"module": sd, "global_steps": 3}, f)
+    back = CK.load_state_dict_file(str(f))
+    assert set(back) == set(sd) and torch.equal(back["proj.latents"], sd["proj.latents"])
+    from safetensors.torch import save_file
+    g = tmp_path / "w.safetensors"
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(g))
+    assert set(CK.load_state_dict_file(str(g))) == set(sd)
+    assert CK.hidden_size_of("up_blocks.1.attentions.0.transformer_blocks.0.attn1.processor", (320, 640, 1280, 1280)) == 1280
+    assert CK.hidden_size_of("down_blocks.1.attentions.0.transformer_blocks.0.attn2.processor", (320, 640, 1280, 1280)) == 640
