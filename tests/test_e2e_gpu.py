@@ -216,7 +216,7 @@ def test_build_engines_from_imagdressing_checkpoint(tmp_path):
     sd_u = E.random_state_dict(E.unet_param_shapes(full), 0)
     sd_r = E.random_state_dict(E.unet_param_shapes(full), 1)
     torch.manual_seed(3)
-    rk = dict(dim=64, depth=2, dim_head=16, heads=4, num_queries=16, embedding_dim=96, output_dim=64, ff_mult=2)
+    rk = dict(dim=64, depth=2, dim_head=64, heads=2, num_queries=16, embedding_dim=96, output_dim=64, ff_mult=2)
     proj = Resampler(**rk)
     adapters = torch.nn.ModuleList(p["e_unet"].attn_processors.values())
     ck = {}
