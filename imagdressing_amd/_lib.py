@@ -42,7 +42,7 @@ class AttnParams(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("D", C.c_int),
         ("L1", C.c_int), ("L1P", C.c_int), ("kv1_bdiv", C.c_int),
         ("L2", C.c_int), ("L2P", C.c_int), ("kv2_bdiv", C.c_int),
-        ("out_ld", C.c_int), ("dtype", C.c_int), ("flags", C.c_int),
+        ("out_ld", C.c_int), ("dtype", C.c_int), ("flags", C.c_int), ("causal", C.c_int),
     ]
 
 
@@ -92,6 +92,8 @@ SYMBOLS = {
     "imd_ddim_cfg_step": (C.c_int, [C.POINTER(DdimParams), C.c_void_p]),
     "imd_timestep_embedding": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "imd_add": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_float, C.c_int, C.c_void_p]),
+    "imd_embed_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_void_p]),
+    "imd_vit_assemble": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "imd_copy2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "imd_f32_to_16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
 }

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
         }
     }
 
+    const bool causal = p.causal != 0;
     float w2 = 0.f;
     if (p.k2 != nullptr && p.scale2 != nullptr) w2 = p.scale2[b];
     const int nph = (w2 != 0.f) ? 2 : 1;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                     // P of the block (inf / NaN patterns included).  Only when some P exceeds 2^OFFS_THR (or on the
                     // first / ragged block) is the block redone on the exact path below.  Saves the 32-value fp32 max
                     // tree and the cross-half-wave exchange on every other block.
-                    bool redo = first || ragged;
+                    bool redo = first || ragged || causal;
                     if (!redo) {
 #pragma unroll
                         for (int kb = 0; kb < KB; ++kb)
@@ -288,13 +289,14 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                     }
                     if (!redo) return;
                 }
-                if (ragged) {     // keys >= L of the last tile contribute nothing
+                if (ragged || causal) {     // keys >= L of the last tile (and, causal: keys after the query) contribute nothing
+                    const int qidx = causal ? q0 + qb * 32 + col : 0x7fffffff;
 #pragma unroll
                     for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int key = t * KT + (k0 + kb) * 32 + 8 * hi + (r & 7) + 16 * (r >> 3);
-                            if (key >= L) s[qb][kb][r] = -INFINITY;
+                            if (key >= L || key > qidx) s[qb][kb][r] = -INFINITY;
                         }
                 }
                 // ---- online softmax (base 2; Q carries the scale) ----
@@ -454,6 +456,7 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     if (p.kv1_bdiv <= 0 || (p.k2 && p.kv2_bdiv <= 0)) return imd_set_error("attention: kv batch divisors must be positive");
     if (p.H > 65535 || p.B > 65535) return imd_set_error("attention: H/B exceed grid limits");
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("attention: unknown dtype %d", p.dtype);
+    if (p.causal && (p.k2 != nullptr || p.L1 != p.N)) return imd_set_error("attention: the causal mask needs a single key set with L1 == N");
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (p.D) {
         case 40:

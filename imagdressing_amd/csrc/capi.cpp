@@ -100,6 +100,18 @@ int imd_layernorm(const imd_layernorm_params* p, void* stream) {
     return imd_launch_layernorm(*p, (hipStream_t)stream);
 }
 
+int imd_embed_tokens(const uint16_t* table, int vocab, const uint16_t* pos, int T, const int64_t* ids, uint16_t* out, long rows, int C,
+                     int dtype, void* stream) {
+    IMD_REQUIRE(table && pos && ids && out, "embed_tokens: null pointer");
+    return imd_launch_embed_tokens(table, vocab, pos, T, ids, out, rows, C, dtype, (hipStream_t)stream);
+}
+
+int imd_vit_assemble(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, uint16_t* out, int B, int P, int C, int dtype,
+                     void* stream) {
+    IMD_REQUIRE(patches && cls && pos && out, "vit_assemble: null pointer");
+    return imd_launch_vit_assemble(patches, cls, pos, out, B, P, C, dtype, (hipStream_t)stream);
+}
+
 int imd_softmax_rows(const float* s, int s_ld, uint16_t* p, int p_ld, int rows, int cols, int dtype, void* stream) {
     IMD_REQUIRE(s && p, "softmax_rows: null pointer");
     return imd_launch_softmax_rows(s, s_ld, p, p_ld, rows, cols, dtype, (hipStream_t)stream);

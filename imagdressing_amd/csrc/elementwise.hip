@@ -95,6 +95,44 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const bf16_t* a, int a_ld, 
     }
 }
 
+// out[r] = table[ids[r]] + pos[r % T]      (8 channels per thread; ids outside [0, vocab) read row 0)
+template <bool F16>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const bf16_t* table, int vocab, const bf16_t* pos, int T, const int64_t* ids,
+                                                           bf16_t* out, long rows, int C) {
+    const int vpr = C / 8;
+    const long total = rows * vpr;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long r = i / vpr;
+        const int c = (int)(i - r * vpr) * 8;
+        long id = ids[r];
+        if (id < 0 || id >= vocab) id = 0;
+        float a[8], b[8];
+        unpack8<F16>(*reinterpret_cast<const uint4*>(table + id * C + c), a);
+        unpack8<F16>(*reinterpret_cast<const uint4*>(pos + (r % T) * C + c), b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        *reinterpret_cast<uint4*>(out + r * C + c) = pack8<F16>(a);
+    }
+}
+
+// out[b][0] = cls + pos[0]; out[b][1 + p] = patches[b][p] + pos[1 + p]
+template <bool F16>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* out, int B, int P, int C) {
+    const int vpr = C / 8;
+    const long total = (long)B * (P + 1) * vpr;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long r = i / vpr;
+        const int c = (int)(i - r * vpr) * 8;
+        const int b = (int)(r / (P + 1)), t = (int)(r - (long)b * (P + 1));
+        float a[8], q[8];
+        unpack8<F16>(t == 0 ? *reinterpret_cast<const uint4*>(cls + c) : *reinterpret_cast<const uint4*>(patches + ((long)b * P + t - 1) * C + c), a);
+        unpack8<F16>(*reinterpret_cast<const uint4*>(pos + (long)t * C + c), q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += q[e];
+        *reinterpret_cast<uint4*>(out + r * C + c) = pack8<F16>(a);
+    }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256) void f32_to_16_kernel(const float* a, bf16_t* out, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = El<F16>::fromf(a[i]);
@@ -132,6 +170,25 @@ int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t*
     else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(add_kernel<false>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, a, a_ld, b, b_ld, out, out_ld, rows, C, b_scale);
     else return imd_set_error("add: unknown dtype %d", dtype);
     return imd_check_launch("add");
+}
+
+int imd_launch_embed_tokens(const bf16_t* table, int vocab, const bf16_t* pos, int T, const int64_t* ids, bf16_t* out, long rows, int C, int dtype, hipStream_t s) {
+    if (rows <= 0 || C <= 0 || vocab <= 0 || T <= 0) return imd_set_error("embed_tokens: empty problem");
+    if (C % 8) return imd_set_error("embed_tokens: C (%d) must be a multiple of 8", C);
+    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(embed_tokens_kernel<true>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, table, vocab, pos, T, ids, out, rows, C);
+    else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(embed_tokens_kernel<false>, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, table, vocab, pos, T, ids, out, rows, C);
+    else return imd_set_error("embed_tokens: unknown dtype %d", dtype);
+    return imd_check_launch("embed_tokens");
+}
+
+int imd_launch_vit_assemble(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* out, int B, int P, int C, int dtype, hipStream_t s) {
+    if (B <= 0 || P <= 0 || C <= 0) return imd_set_error("vit_assemble: empty problem");
+    if (C % 8) return imd_set_error("vit_assemble: C (%d) must be a multiple of 8", C);
+    const long work = (long)B * (P + 1) * (C / 8);
+    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(vit_assemble_kernel<true>, dim3(grid_for(work)), dim3(256), 0, s, patches, cls, pos, out, B, P, C);
+    else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(vit_assemble_kernel<false>, dim3(grid_for(work)), dim3(256), 0, s, patches, cls, pos, out, B, P, C);
+    else return imd_set_error("vit_assemble: unknown dtype %d", dtype);
+    return imd_check_launch("vit_assemble");
 }
 
 int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C, hipStream_t s) {

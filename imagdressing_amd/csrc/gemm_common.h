@@ -94,6 +94,9 @@ __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int
     } else if (p.act == ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
+    } else if (p.act == ACT_QUICK_GELU) {      // x * sigmoid(1.702 x) = silu(1.702 x) / 1.702
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = silu_f(1.702f * v[e]) * (1.0f / 1.702f);
     }
     if (p.mode == OUT_HEADS) {
         const int which = n / p.hC;

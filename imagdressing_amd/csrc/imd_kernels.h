@@ -14,7 +14,7 @@ typedef imd_groupnorm_params GroupNormParams;
 typedef imd_layernorm_params LayerNormParams;
 typedef imd_ddim_params DdimParams;
 
-enum { ACT_NONE = IMD_ACT_NONE, ACT_SILU = IMD_ACT_SILU, ACT_GEGLU = IMD_ACT_GEGLU, ACT_GELU = IMD_ACT_GELU };
+enum { ACT_NONE = IMD_ACT_NONE, ACT_SILU = IMD_ACT_SILU, ACT_GEGLU = IMD_ACT_GEGLU, ACT_GELU = IMD_ACT_GELU, ACT_QUICK_GELU = IMD_ACT_QUICK_GELU };
 enum { OUT_ROWMAJOR = IMD_OUT_ROWMAJOR, OUT_HEADS = IMD_OUT_HEADS };
 
 // error plumbing (thread-local message, surfaced by imd_last_error())
@@ -39,5 +39,7 @@ int imd_launch_softmax_rows(const float* s_in, int s_ld, bf16_t* p_out, int p_ld
 int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s);
 int imd_launch_timestep_embedding(const float* t, float* out, int B, int dim, hipStream_t s);
 int imd_launch_add(const bf16_t* a, int a_ld, const bf16_t* b, int b_ld, bf16_t* out, int out_ld, long rows, int C, float b_scale, int dtype, hipStream_t s);
+int imd_launch_embed_tokens(const bf16_t* table, int vocab, const bf16_t* pos, int T, const int64_t* ids, bf16_t* out, long rows, int C, int dtype, hipStream_t s);
+int imd_launch_vit_assemble(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* out, int B, int P, int C, int dtype, hipStream_t s);
 int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C, hipStream_t s);
 int imd_launch_f32_to_16(const float* a, bf16_t* out, long n, int dtype, hipStream_t s);

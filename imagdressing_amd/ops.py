@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 
-ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GELU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_GELU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 bf16 = torch.bfloat16
 f16 = torch.float16
 DTYPE_CODE = {torch.bfloat16: 0, torch.float16: 1}     # IMD_DTYPE_*
@@ -238,7 +238,7 @@ ATTN_EVENT_HOOK = None
 
 
 def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=None, scale2=None,
-              L2=0, L2P=0, kv2_bdiv=1, out_ld=None):
+              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False):
     ensure_device(q.device)
     p = L.AttnParams()
     dt = q.dtype
@@ -251,6 +251,7 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
     p.L1, p.L1P, p.kv1_bdiv = L1, L1P, kv1_bdiv
     p.L2, p.L2P, p.kv2_bdiv = L2, L2P, kv2_bdiv
     p.out_ld = H * D if out_ld is None else out_ld
+    p.causal = int(causal)
     hook = ATTN_EVENT_HOOK
     if hook is not None and hook["match"](B=B, H=H, N=N, D=D, L1=L1, L2=L2 if k2 is not None else 0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -303,6 +304,27 @@ def group_norm_coeffs(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5):
     p.eps, p.silu = eps, 0
     L.check(lib.imd_groupnorm_coeffs(C.byref(p), ab[0].data_ptr(), ab[1].data_ptr(), _stream()))
     return ab[0], ab[1]
+
+
+def embed_tokens(table: torch.Tensor, pos: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+    """table [V, C], pos [T, C] 16-bit, ids [B, T] int64 -> [B, T, C] = table[ids] + pos."""
+    ensure_device(table.device)
+    B, T = ids.shape
+    V, Cc = table.shape
+    out = torch.empty((B, T, Cc), dtype=table.dtype, device=table.device)
+    L.check(L.load().imd_embed_tokens(_dev(table, table.dtype, "table"), V, _dev(pos, table.dtype, "pos"), pos.shape[0],
+                                      _dev(ids, torch.int64, "ids"), out.data_ptr(), B * T, Cc, _code(table, "table"), _stream()))
+    return out
+
+
+def vit_assemble(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """patches [B, P, C], cls [C], pos [P + 1, C] -> [B, P + 1, C] (class token first, position embeddings added)."""
+    ensure_device(patches.device)
+    B, P, Cc = patches.shape
+    out = torch.empty((B, P + 1, Cc), dtype=patches.dtype, device=patches.device)
+    L.check(L.load().imd_vit_assemble(_dev(patches, patches.dtype, "patches"), _dev(cls, patches.dtype, "cls"), _dev(pos, patches.dtype, "pos"),
+                                      out.data_ptr(), B, P, Cc, _code(patches, "patches"), _stream()))
+    return out
 
 
 def softmax_rows(s: torch.Tensor, dtype=bf16, out=None) -> torch.Tensor:

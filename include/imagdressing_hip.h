@@ -27,7 +27,7 @@ extern "C" {
 
 #define IMD_ABI_VERSION 1
 
-enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3 };
+enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
 /* 16-bit element type of activations and weights (both run v_mfma_f32_32x32x16_* at the same rate) */
 enum { IMD_DTYPE_BF16 = 0, IMD_DTYPE_F16 = 1 };
@@ -87,6 +87,7 @@ typedef struct imd_attn_params {
     int out_ld;
     int dtype;
     int flags;           /* filled in by the library (tuning bits) */
+    int causal;          /* 1: query i attends keys 0..i of the first key set only (CLIP text encoder); needs k2 == NULL, D != 40 */
 } imd_attn_params;
 
 typedef struct imd_groupnorm_params {
@@ -178,6 +179,12 @@ int imd_timestep_embedding(const float* t, float* out, int B, int dim, void* str
  * ..._pipeline_ipa_controlnet.py:676-677,687-688; skip + residual). */
 int imd_add(const uint16_t* a, int a_ld, const uint16_t* b, int b_ld, uint16_t* out, int out_ld, long rows, int C, float b_scale, int dtype, void* stream);
 /* strided 2-D copy (channel concat of UNet skip connections). */
+/* Token + position embedding lookup (CLIPTextEmbeddings): out[r][:] = table[ids[r]][:] + pos[r % T][:]; ids are int64. */
+int imd_embed_tokens(const uint16_t* table, int vocab, const uint16_t* pos, int T, const int64_t* ids, uint16_t* out, long rows, int C,
+                     int dtype, void* stream);
+/* ViT sequence assembly (CLIPVisionEmbeddings): out[b][0] = cls + pos[0]; out[b][1 + p] = patches[b][p] + pos[1 + p]. */
+int imd_vit_assemble(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, uint16_t* out, int B, int P, int C, int dtype,
+                     void* stream);
 int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows, int C, void* stream);
 /* fp32 -> 16-bit element cast (round to nearest even). */
 int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream);
