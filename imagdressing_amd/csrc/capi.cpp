@@ -112,6 +112,11 @@ int imd_vit_assemble(const uint16_t* patches, const uint16_t* cls, const uint16_
     return imd_launch_vit_assemble(patches, cls, pos, out, B, P, C, dtype, (hipStream_t)stream);
 }
 
+int imd_lincomb(const float* const* xs, const float* coefs, int n, float* out, long numel, void* stream) {
+    IMD_REQUIRE(xs && coefs && out, "lincomb: null pointer");
+    return imd_launch_lincomb(xs, coefs, n, out, numel, (hipStream_t)stream);
+}
+
 int imd_softmax_rows(const float* s, int s_ld, uint16_t* p, int p_ld, int rows, int cols, int dtype, void* stream) {
     IMD_REQUIRE(s && p, "softmax_rows: null pointer");
     return imd_launch_softmax_rows(s, s_ld, p, p_ld, rows, cols, dtype, (hipStream_t)stream);

@@ -133,6 +133,29 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(const bf16_t* patches
     }
 }
 
+struct LincombArgs { const float* x[8]; float c[8]; int n; };
+__global__ __launch_bounds__(256) void lincomb_kernel(const LincombArgs a, float* out, long n4, long numel) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+        const long e = i * 4;
+        if (e + 4 <= numel) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < a.n) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.x[j] + e);
+                    acc.x = fmaf(a.c[j], v.x, acc.x); acc.y = fmaf(a.c[j], v.y, acc.y); acc.z = fmaf(a.c[j], v.z, acc.z); acc.w = fmaf(a.c[j], v.w, acc.w);
+                }
+            *reinterpret_cast<float4*>(out + e) = acc;
+        } else {
+            for (long k = e; k < numel; ++k) {
+                float acc = 0.f;
+                for (int j = 0; j < a.n; ++j) acc = fmaf(a.c[j], a.x[j][k], acc);
+                out[k] = acc;
+            }
+        }
+    }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(256) void f32_to_16_kernel(const float* a, bf16_t* out, long n) {
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) out[i] = El<F16>::fromf(a[i]);
@@ -189,6 +212,20 @@ int imd_launch_vit_assemble(const bf16_t* patches, const bf16_t* cls, const bf16
     else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(vit_assemble_kernel<false>, dim3(grid_for(work)), dim3(256), 0, s, patches, cls, pos, out, B, P, C);
     else return imd_set_error("vit_assemble: unknown dtype %d", dtype);
     return imd_check_launch("vit_assemble");
+}
+
+int imd_launch_lincomb(const float* const* xs, const float* coefs, int n, float* out, long numel, hipStream_t s) {
+    if (n < 1 || n > 8) return imd_set_error("lincomb: 1..8 inputs (got %d)", n);
+    if (numel <= 0) return imd_set_error("lincomb: empty tensor");
+    LincombArgs a;
+    for (int j = 0; j < 8; ++j) { a.x[j] = j < n ? xs[j] : nullptr; a.c[j] = j < n ? coefs[j] : 0.f; }
+    a.n = n;
+    for (int j = 0; j < n; ++j)
+        if (a.x[j] == nullptr || (reinterpret_cast<uintptr_t>(a.x[j]) & 15)) return imd_set_error("lincomb: input %d is null or not 16-byte aligned", j);
+    if (reinterpret_cast<uintptr_t>(out) & 15) return imd_set_error("lincomb: output is not 16-byte aligned");
+    const long n4 = (numel + 3) / 4;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(grid_for(n4)), dim3(256), 0, s, a, out, n4, numel);
+    return imd_check_launch("lincomb");
 }
 
 int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C, hipStream_t s) {

@@ -179,12 +179,25 @@ class PipelineBase:
                 return t.permute(0, 2, 3, 1).reshape(B, HW, c).contiguous()
             inp = dict(mask=nhwc(inpaint["mask"], 1).view(B, HW).contiguous(), z_img=nhwc(inpaint["image_latents"], Cl),
                        noise=nhwc(inpaint["noise"], Cl))
+        multistep = hasattr(sch, "step_guided")        # UniPC: latent updates are host-computed linear combinations
+        if multistep and inp is not None:
+            raise NotImplementedError("the inpainting blend is defined on the DDIM step (…inpainting.py:487-500)")
         for i, t in enumerate(timesteps):
             down = mid = None
             if control is not None:
                 keep = control.get("keep", [1.0] * len(timesteps))[i]
                 down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, float(control.get("scale", 1.0)) * keep)
             eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid)
+            if multistep:
+                z = sch.step_guided(eps.view(2 * B, HW, Cl), z, float(guidance_scale))
+                # emit the next 16-bit UNet input (both CFG halves) from z: the fused step with eps = 0, alpha = 1 is the identity on z
+                ops.ddim_cfg_step(z, ops.workspace("zero_eps", (2 * B, HW, Cl), torch.float32, dev), x_in.view(2 * B, HW, 8),
+                                  guidance=1.0, a_t=1.0, a_prev=1.0)
+                if trace is not None:
+                    trace.append(z.clone())
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, z.view(B, h, w, Cl).permute(0, 3, 1, 2))
+                continue
             kw = {}
             if inp is not None:
                 a_next = sch.alpha(timesteps[i + 1]) if i < len(timesteps) - 1 else None

@@ -306,6 +306,22 @@ def group_norm_coeffs(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5):
     return ab[0], ab[1]
 
 
+def lincomb(terms, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum_j c_j * x_j over 1..8 (coefficient, fp32 tensor) pairs of equal numel; ``out`` may be one of the inputs."""
+    xs = [t for _, t in terms]
+    ensure_device(xs[0].device)
+    n, numel = len(terms), xs[0].numel()
+    for t in xs:
+        if t.numel() != numel:
+            raise L.ImdError("lincomb: all tensors must have the same number of elements")
+    if out is None:
+        out = torch.empty_like(xs[0])
+    ptrs = (C.c_void_p * n)(*[_dev(t, torch.float32, "lincomb input") for t in xs])
+    coefs = (C.c_float * n)(*[float(c) for c, _ in terms])
+    L.check(L.load().imd_lincomb(ptrs, coefs, n, _dev(out, torch.float32, "out"), numel, _stream()))
+    return out
+
+
 def embed_tokens(table: torch.Tensor, pos: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
     """table [V, C], pos [T, C] 16-bit, ids [B, T] int64 -> [B, T, C] = table[ids] + pos."""
     ensure_device(table.device)

@@ -185,6 +185,9 @@ int imd_embed_tokens(const uint16_t* table, int vocab, const uint16_t* pos, int 
 /* ViT sequence assembly (CLIPVisionEmbeddings): out[b][0] = cls + pos[0]; out[b][1 + p] = patches[b][p] + pos[1 + p]. */
 int imd_vit_assemble(const uint16_t* patches, const uint16_t* cls, const uint16_t* pos, uint16_t* out, int B, int P, int C, int dtype,
                      void* stream);
+/* out[i] = sum_j coefs[j] * xs[j][i] over n <= 8 fp32 tensors of `numel` elements (xs / coefs are HOST arrays; out may alias an
+ * input): the latent arithmetic of the multistep UniPC sampler (x0 prediction with CFG, predictor and corrector updates). */
+int imd_lincomb(const float* const* xs, const float* coefs, int n, float* out, long numel, void* stream);
 int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows, int C, void* stream);
 /* fp32 -> 16-bit element cast (round to nearest even). */
 int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream);

@@ -239,3 +239,48 @@ def test_build_engines_from_imagdressing_checkpoint(tmp_path):
     assert torch.equal(outs[0], outs[1])
     clip = g(7, 1, 20, 96, scale=0.5).cuda().to(dt)
     assert torch.equal(eng["image_proj"](clip), proj.to(device="cuda", dtype=dt)(clip))
+
+
+@torch.no_grad()
+def test_pipeline_unipc_sampler_small():
+    """UniPC through the pipeline == the same coefficient lists applied by hand in fp64 to the same UNet
+    outputs (the scheduler's host math is tested separately on the CPU); 10 steps beat nothing here -- this checks plumbing:
+    CFG folded into the x0 prediction, history handling, the emitted 16-bit UNet input."""
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+    from imagdressing_amd.scheduler import UniPCMultistepScheduler
+    dt = torch.float16
+    p = build_pair(SMALL, seed=0, dtype=dt)
+    mk = lambda: UniPCMultistepScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")   # noqa: E731
+
+    class Proj:
+        def __call__(self, h):
+            return h
+    sch = mk()
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           image_encoder=None, ImgProj=Proj(), scheduler=sch, safety_checker=None, feature_extractor=None)
+    lat = g(20, 2, 4, 16, 16)
+    steps, gs = 6, 7.5
+    trace = []
+    kw = dict(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=128, height=128, num_inference_steps=steps,
+              guidance_scale=gs, num_images_per_prompt=2, prompt_embeds=g(10, 1, 77, 64, scale=0.5).cuda(),
+              negative_prompt_embeds=g(11, 1, 77, 64, scale=0.5).cuda(), ref_clip_hidden_states=g(12, 1, 16, 64, scale=0.5).cuda(),
+              ref_image_latents=g(13, 1, 4, 16, 16).cuda(), latents=lat.cuda(), output_type="latent")
+    out = pipe(trace=trace, **kw).images
+    assert torch.isfinite(out).all() and len(trace) == steps
+    assert [int(t) for t in sch.timesteps] == [999, 832, 666, 500, 333, 166]
+    # deterministic and restartable (set_timesteps resets the history)
+    assert torch.equal(pipe(**kw).images, out)
+    # the first step has no history: it is the DDIM update from sigma(999) to sigma(832) with the guided epsilon
+    ref = mk(); ref.set_timesteps(steps)
+    a0, s0 = ref._alpha_sigma(0); a1, s1 = ref._alpha_sigma(1)
+    z0 = lat.cuda().permute(0, 2, 3, 1).reshape(2, 256, 4)
+    from imagdressing_amd.unet import nchw_to_nhwc8
+    x_in = torch.cat([nchw_to_nhwc8(lat.cuda(), dt)] * 2)
+    p["e_ref"].forward_nhwc(nchw_to_nhwc8(kw["ref_image_latents"], dt), 0, kw["ref_clip_hidden_states"].to(dt).contiguous())
+    sa = {n: pr.cache["hidden_states"] for n, pr in p["e_ref"].attn_processors.items()}
+    ehs = torch.cat([kw["prompt_embeds"], kw["negative_prompt_embeds"]]).to(dt).contiguous()
+    mask = torch.cat([torch.ones(2), torch.zeros(2)]).cuda()
+    eps = p["e_unet"].forward_nhwc(x_in, 999, ehs, {"sa_hidden_states": sa, "sa_batch_mask": mask}).view(4, 256, 4).double()
+    e = gs * eps[:2] + (1 - gs) * eps[2:]
+    want = a1 * (z0.double() - s0 * e) / a0 + s1 * e
+    assert torch.allclose(trace[0].double(), want, rtol=1e-4, atol=1e-4)

@@ -211,3 +211,81 @@ def test_imagdressing_checkpoint_split_and_file_roundtrip(tmp_path):
     assert set(CK.load_state_dict_file(str(g))) == set(sd)
     assert CK.hidden_size_of("up_blocks.1.attentions.0.transformer_blocks.0.attn1.processor", (320, 640, 1280, 1280)) == 1280
     assert CK.hidden_size_of("down_blocks.1.attentions.0.transformer_blocks.0.attn2.processor", (320, 640, 1280, 1280)) == 640
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# UniPC multistep sampler: host-side coefficient math, applied here with numpy
+# ---------------------------------------------------------------------------------------------------------------------
+def _unipc_run(order, N, corrector, stop, model, x, lower_order_final=False):
+    """drive UniPCMultistepScheduler's coefficient lists exactly as `_advance` does, on numpy vectors"""
+    import numpy as np
+    from imagdressing_amd.scheduler import UniPCMultistepScheduler
+    sch = UniPCMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", solver_order=order,
+                                  disable_corrector=() if corrector else tuple(range(N)), lower_order_final=lower_order_final)
+    sch.set_timesteps(N)
+    for pos in range(stop):
+        a, s = sch._alpha_sigma(pos)
+        named = {"x": x, "eps": model(x, a, s)}
+        mt = sum(c * named[n] for c, n in sch.x0_terms(pos))
+        sch.step_index = pos
+        hist = {f"m{k}": m for k, m in enumerate(reversed(sch.model_outputs))}
+        if pos > 0 and (pos - 1) not in sch.disable_corrector and sch.last_sample is not None:
+            d = dict(hist, x=sch.last_sample, mt=mt)
+            x = sum(c * d[n] for c, n in sch.corrector_terms(pos, sch.this_order))
+        sch.model_outputs = (sch.model_outputs + [mt])[-order:]
+        sch.ts_hist = (sch.ts_hist + [pos])[-order:]
+        sch.this_order = sch._order_now()
+        sch.last_sample = x
+        hist = {f"m{k}": m for k, m in enumerate(reversed(sch.model_outputs))}
+        d = dict(hist, x=x)
+        x = sum(c * d[n] for c, n in sch.predictor_terms(pos, sch.this_order))
+        if sch.lower_order_nums < order:
+            sch.lower_order_nums += 1
+    return sch, x
+
+
+def test_unipc_convergence_orders_on_the_gaussian_case():
+    """Data ~ N(0, s^2): the optimal denoiser is linear and the probability-flow ODE has the closed form
+    x_t = x_T sqrt(a_t^2 s^2 + sigma_t^2) / sqrt(a_T^2 s^2 + sigma_T^2).  On the smooth first half of the schedule the global
+    error must fall like N^-1 (UniP-1 = DDIM), N^-2 (UniP-1 + UniC, UniP-2), N^-3 (UniPC-2), N^-4 (UniPC-3)."""
+    import numpy as np
+    sd = 0.7
+
+    def model(x, a, s):
+        return (x - a * (a * sd * sd / (a * a * sd * sd + s * s)) * x) / s
+
+    def err(order, N, corr):
+        x0 = np.array([1.3, -0.4, 2.0])
+        sch, x = _unipc_run(order, N, corr, N // 2, model, x0.copy())
+        a0, s0 = sch._alpha_sigma(0); a1, s1 = sch._alpha_sigma(N // 2)
+        exact = x0 * np.sqrt(a1 * a1 * sd * sd + s1 * s1) / np.sqrt(a0 * a0 * sd * sd + s0 * s0)
+        return np.abs(x - exact).max() / np.abs(exact).max()
+    for order, corr, rate in ((1, False, 1), (1, True, 2), (2, False, 2), (2, True, 3), (3, True, 4)):
+        e40, e80 = err(order, 40, corr), err(order, 80, corr)
+        assert 2 ** rate * 0.6 < e40 / e80 < 2 ** rate * 1.6, (order, corr, e40, e80)
+    assert err(2, 40, True) < 1e-4 < err(1, 40, False)
+
+
+def test_unipc_order1_is_ddim_and_constant_prediction_is_exact():
+    import numpy as np
+    rng = np.random.default_rng(0)
+    x0 = rng.standard_normal(5)
+    # (1) order 1, no corrector: every step is the deterministic DDIM update x' = a' x0_pred + s' eps
+    eps_fix = rng.standard_normal(5)
+    sch, x1 = _unipc_run(1, 10, False, 1, lambda x, a, s: eps_fix, x0.copy())
+    a, s = sch._alpha_sigma(0); a2, s2 = sch._alpha_sigma(1)
+    ddim = a2 * (x0 - s * eps_fix) / a + s2 * eps_fix
+    assert np.allclose(x1, ddim, rtol=1e-12, atol=1e-12)
+    # (2) a model whose data prediction is the constant c is integrated exactly by every order (all differences vanish)
+    c = rng.standard_normal(5)
+    for order in (1, 2, 3):
+        sch, x = _unipc_run(order, 12, True, 12, lambda x, a, s: (x - a * c) / s, x0.copy(), lower_order_final=True)
+        a0, s0 = sch._alpha_sigma(0); aT, sT = sch._alpha_sigma(12)
+        assert np.allclose(x, sT / s0 * (x0 - a0 * c) + aT * c, rtol=1e-9, atol=1e-9)
+    # timesteps: "linspace" spacing of diffusers (50 steps: 999, 979, ..., 20), final sigma = that of training timestep 0
+    from imagdressing_amd.scheduler import UniPCMultistepScheduler
+    s50 = UniPCMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    s50.set_timesteps(50)
+    ts = [int(t) for t in s50.timesteps]
+    assert ts[0] == 999 and ts[-1] == 20 and len(ts) == 50 and all(a > b for a, b in zip(ts, ts[1:]))
+    assert abs(s50._sig[-1] - ((1 - float(s50._ac[0])) / float(s50._ac[0])) ** 0.5) < 1e-12

@@ -388,3 +388,17 @@ def test_no_cpu_fallback(ops):
     from imagdressing_amd._lib import ImdError
     with pytest.raises(ImdError):
         ops.linear(torch.zeros(8, 8, dtype=bf16), torch.zeros(8, 8, dtype=bf16))
+
+
+def test_lincomb(ops):
+    xs = [dev(rnd(i, 3, 1000, 4)) for i in range(5)]
+    cs = [0.5, -1.25, 2.0, 0.0, 1e-3]
+    out = ops.lincomb(list(zip(cs, xs)))
+    ref = sum(c * x for c, x in zip(cs, xs))
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-6)
+    ops.lincomb([(2.0, xs[0]), (1.0, xs[1])], out=xs[0])            # in place
+    assert torch.allclose(xs[0], 2.0 * dev(rnd(0, 3, 1000, 4)) + xs[1], rtol=1e-6, atol=1e-6)
+    odd = [dev(rnd(9, 1001)), dev(rnd(10, 1001))]                    # numel % 4 != 0: scalar tail
+    assert torch.allclose(ops.lincomb([(1.0, odd[0]), (-3.0, odd[1])]), odd[0] - 3.0 * odd[1], rtol=1e-6, atol=1e-6)
+    with pytest.raises(ops.L.ImdError):
+        ops.lincomb([(1.0, xs[0])] * 9)
