@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-steps", type=int, default=1)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL; gloo only for single-GPU rehearsals of N > 1)")
+    ap.add_argument("--device", type=int, default=-1, help="force the HIP device index of every rank (rehearsal of N > 1 on one GPU)")
     ap.add_argument("--decode", action="store_true",
                     help="also run the HIP VAE decoder (SURVEY 8f rank 1) on the final latents inside the timed region")
     ap.add_argument("--attn-qw", type=int, default=0, help="tuning knob 0 of the library (0 = library default)")
@@ -177,13 +179,17 @@ def main():
         if rank == 0 and world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}", file=sys.stderr)
             sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if args.device < 0 else args.device
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)     # "nccl" == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)     # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=args.backend)
 
     from imagdressing_amd import dist as imd_dist
     from imagdressing_amd import ops
