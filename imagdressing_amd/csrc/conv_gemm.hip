@@ -44,14 +44,15 @@ template <int BM, int BN, int BK, int WAVES_M> struct TileCfg {
 // VAR: main-loop schedule.  0 = fragments read per 16-deep k step; 1 = all fragments of the tile read up front
 //      (one LDS latency per tile instead of four) -- needs 64 more VGPRs, only for the 128x128 tile.
 template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int VAR, int DEPTH>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2 : 1) void conv_gemm_kernel(const ConvGemmParams p) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;      // threads per workgroup: 256 (4 waves) or 512 (8 waves: the 256-row tiles)
     using E = El<F16>;
     using T = TileCfg<BM, BN, BK, WAVES_M>;
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     constexpr int STRIDE = T::STRIDE;
     constexpr int VPR = BK / 8;                // 16-B vectors per row
-    constexpr int RSTEP = 256 / VPR;           // rows covered by one pass of the 256 threads
+    constexpr int RSTEP = NT / VPR;            // rows covered by one pass of the workgroup's threads
     constexpr int A_VECS = BM / RSTEP;
     constexpr int W_VECS = BN / RSTEP;
     constexpr int BUF = (BM + BN) * STRIDE;
@@ -249,6 +250,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
     constexpr int CHUNKS = T::EROWS * CPR;
     const bool colmajor = p.mode == OUT_HEADS;  // consecutive threads -> consecutive tokens (coalesces V^T / Q / K rows)
     float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)split * p.M * p.N : nullptr;
+    // bias / per-batch vector of this thread's 8 columns, fetched once (row-major epilogue: the column block of a thread
+    // does not change from row to row when the thread count is a multiple of the chunks per row)
+    constexpr bool COLS_FIXED = (NT % CPR) == 0;
+    float4 col_pre0 = make_float4(0, 0, 0, 0), col_pre1 = col_pre0;
+    bool use_col_pre = false;
+    if (COLS_FIXED && !colmajor && slab == nullptr && (p.bias || p.rowvec)) {
+        const int bi_lo = m0 / HWo, bi_hi = (min(m0 + BM, p.M) - 1) / HWo;
+        const int n = n0 + (tid % CPR) * 8;
+        if ((p.rowvec == nullptr || bi_lo == bi_hi) && n < p.N) {
+            load_col_addends(p, p.rowvec ? bi_lo : -1, n, (n + 8 <= p.N) ? 8 : 4, col_pre0, col_pre1);
+            use_col_pre = true;
+        }
+    }
 #pragma unroll 1
     for (int wr = 0; wr < WAVES_M; ++wr) {
         if (wave / WAVES_N == wr) {
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                     }
         }
         __syncthreads();
-        for (int c = tid; c < CHUNKS; c += 256) {
+        for (int c = tid; c < CHUNKS; c += NT) {
             int row, cc;
             if (colmajor) { cc = (c / T::EROWS) * 8; row = c - (c / T::EROWS) * T::EROWS; }
             else { row = c / CPR; cc = (c - row * CPR) * 8; }
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvGemmParams 
                 if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
             } else {
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo);
+                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo, use_col_pre, col_pre0, col_pre1);
             }
         }
         if (wr + 1 < WAVES_M) __syncthreads();
@@ -323,7 +337,7 @@ int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
         attr_set = true;
     }
     const long mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(WM * WN * 64), lds, s, p);
     int rc = imd_check_launch("conv_gemm");
     if (rc || p.split_k <= 1) return rc;
     const long chunks = (long)p.M * ((p.N + 7) / 8);
@@ -341,6 +355,8 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 4: case 5: case 8: *bm = 128; *bn = 128; return 0;
         case 3: case 7: *bm = 64; *bn = 64; return 0;
         case 6: *bm = 64; *bn = 320; return 0;
+        case 9: *bm = 256; *bn = 128; return 0;
+        case 10: *bm = 256; *bn = 256; return 0;
         default: return 1;
     }
 }
@@ -431,6 +447,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 6: return h ? launch_cfg<true, 64, 320, 32, 2, 2>(p, s) : launch_cfg<false, 64, 320, 32, 2, 2>(p, s);               // N % 320 == 0: no idle columns, A read once
         case 7: return h ? launch_cfg<true, 64, 64, 32, 2, 2, 0, 4>(p, s) : launch_cfg<false, 64, 64, 32, 2, 2, 0, 4>(p, s);       // 20 KB LDS: 8 workgroups / CU
         case 8: return h ? launch_cfg<true, 128, 128, 32, 2, 2, 0, 4>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2, 0, 4>(p, s);
+        case 9: return h ? launch_cfg<true, 256, 128, 32, 4, 2>(p, s) : launch_cfg<false, 256, 128, 32, 4, 2>(p, s);             // 8 waves: operand bytes per MFMA -25 %
+        case 10: return h ? launch_cfg<true, 256, 256, 32, 4, 2>(p, s) : launch_cfg<false, 256, 256, 32, 4, 2>(p, s);            // 8 waves, 64x128 per wave: -50 %
         case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
             int rc = imd_launch_conv_patch(p, s);
             if (rc || p.split_k <= 1) return rc;

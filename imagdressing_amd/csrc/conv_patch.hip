@@ -218,6 +218,16 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     constexpr int CHUNKS = EROWS * CPR;
     const int HW = H * W;
     float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)split * p.M * p.N : nullptr;
+    // bias / time-embedding vector of this thread's 8 columns, fetched once (see epilogue8): the tile lies in ONE image
+    float4 col_pre0 = make_float4(0, 0, 0, 0), col_pre1 = col_pre0;
+    bool use_col_pre = false;
+    if (slab == nullptr && (p.bias || p.rowvec)) {
+        const int n = n0 + (tid % CPR) * 8;
+        if (n < p.N) {
+            load_col_addends(p, p.rowvec ? b : -1, n, (n + 8 <= p.N) ? 8 : 4, col_pre0, col_pre1);
+            use_col_pre = true;
+        }
+    }
 #pragma unroll 1
     for (int wr = 0; wr < 2; ++wr) {
         if ((wave >> 1) == wr) {
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
                 if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
             } else {
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HW);
+                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HW, use_col_pre, col_pre0, col_pre1);
             }
         }
         if (wr == 0) __syncthreads();
