@@ -63,17 +63,25 @@ def test_vae_small_encode_decode_vs_oracle(gpu, dt):
     assert s.shape == dist.mean.shape and torch.isfinite(s).all()
 
 
-@DTS
-@torch.no_grad()
-def test_vae_full_width_decode_vs_oracle(gpu, dt):
-    """the real 49.5 M-parameter decoder (channels 512/512/256/128, d = 512 mid attention) on a 32x32 latent -> 256x256"""
-    from imagdressing_amd.vae import AutoencoderKL
+@pytest.fixture(scope="module")
+def full_vae_oracle(gpu):
+    """(state dict, latent, fp32 oracle decode) of the real 49.5 M-parameter decoder, computed once for both dtypes"""
     from oracle import vae as OV
     sd = OV.seeded_state_dict(None, seed=3)
     o = OV.AutoencoderKL(); o.load_state_dict(sd, strict=True)
-    e = AutoencoderKL(sd, None, "cuda", dt)
     z = rnd(4, 1, 4, 32, 32)
-    ref = o.decode(z)
+    with torch.no_grad():
+        ref = o.decode(z)
+    return sd, z, ref
+
+
+@DTS
+@torch.no_grad()
+def test_vae_full_width_decode_vs_oracle(full_vae_oracle, dt):
+    """the real decoder (channels 512/512/256/128, d = 512 mid attention) on a 32x32 latent -> 256x256"""
+    from imagdressing_amd.vae import AutoencoderKL
+    sd, z, ref = full_vae_oracle
+    e = AutoencoderKL(sd, None, "cuda", dt)
     got = e.decode(z.cuda(), return_dict=False)[0]
     st = stats(got, ref)
     b = bars(dt)
