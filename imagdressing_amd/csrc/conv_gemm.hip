@@ -41,9 +41,7 @@ template <int BM, int BN, int BK, int WAVES_M> struct TileCfg {
     static constexpr int LDS = MAIN > EPI ? MAIN : EPI;
 };
 
-// VAR: main-loop schedule.  0 = fragments read per 16-deep k step; 1 = all fragments of the tile read up front
-//      (one LDS latency per tile instead of four) -- needs 64 more VGPRs, only for the 128x128 tile.
-template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int VAR, int DEPTH>
+template <bool F16, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int DEPTH>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 2 : 1) void conv_gemm_kernel(const ConvGemmParams p) {
     constexpr int NT = WAVES_M * WAVES_N * 64;      // threads per workgroup: 256 (4 waves) or 512 (8 waves: the 256-row tiles)
     using E = El<F16>;
@@ -194,29 +192,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 
             for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
     };
     auto mma_tile = [&](int buf) {
-        if (VAR == 0) {
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) mma(buf, kk);
-        } else {
-            const char* As = smem + buf * BUF;
-            const char* Ws = As + BM * STRIDE;
-            uint4 wf[BK / 16][TN], xf[BK / 16][TM];
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-#pragma unroll
-                for (int a = 0; a < TN; ++a)
-                    wf[kk][a] = *reinterpret_cast<const uint4*>(Ws + (wn0 + a * 32) * STRIDE + frag_off + kk * 32);
-#pragma unroll
-                for (int b = 0; b < TM; ++b)
-                    xf[kk][b] = *reinterpret_cast<const uint4*>(As + (wm0 + b * 32) * STRIDE + frag_off + kk * 32);
-            }
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk)
-#pragma unroll
-                for (int a = 0; a < TN; ++a)
-#pragma unroll
-                    for (int b = 0; b < TM; ++b) acc[a][b] = E::mfma(wf[kk][a], xf[kk][b], acc[a][b]);
-        }
+        for (int kk = 0; kk < BK / 16; ++kk) mma(buf, kk);
     };
 
     // Software pipeline (tiles past the K range read as zero, so the steady state needs no guards):
@@ -325,12 +302,12 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams
     }
 }
 
-template <bool F16, int BM, int BN, int BK, int WM, int WN, int VAR = 0, int DEPTH = 2>
+template <bool F16, int BM, int BN, int BK, int WM, int WN, int DEPTH = 2>
 int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     static_assert(DEPTH == 2 || DEPTH == 4, "pipeline depth");
     constexpr int lds = TileCfg<BM, BN, BK, WM>::LDS;
     static bool attr_set = false;
-    auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN, VAR, DEPTH>;
+    auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN, DEPTH>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -442,11 +419,11 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 0: return h ? launch_cfg<true, 128, 128, 64, 2, 2>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2>(p, s);
         case 1: return h ? launch_cfg<true, 128, 64, 64, 2, 2>(p, s) : launch_cfg<false, 128, 64, 64, 2, 2>(p, s);
         case 2: return h ? launch_cfg<true, 64, 64, 64, 2, 2>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2>(p, s);
-        case 3: return h ? launch_cfg<true, 64, 64, 64, 2, 2, 0, 4>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2, 0, 4>(p, s);       // 4 tiles in flight
+        case 3: return h ? launch_cfg<true, 64, 64, 64, 2, 2, 4>(p, s) : launch_cfg<false, 64, 64, 64, 2, 2, 4>(p, s);       // 4 tiles in flight
         case 4: return h ? launch_cfg<true, 128, 128, 32, 2, 2>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2>(p, s);         // 41 KB LDS: 3 workgroups / CU
         case 6: return h ? launch_cfg<true, 64, 320, 32, 2, 2>(p, s) : launch_cfg<false, 64, 320, 32, 2, 2>(p, s);               // N % 320 == 0: no idle columns, A read once
-        case 7: return h ? launch_cfg<true, 64, 64, 32, 2, 2, 0, 4>(p, s) : launch_cfg<false, 64, 64, 32, 2, 2, 0, 4>(p, s);       // 20 KB LDS: 8 workgroups / CU
-        case 8: return h ? launch_cfg<true, 128, 128, 32, 2, 2, 0, 4>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2, 0, 4>(p, s);
+        case 7: return h ? launch_cfg<true, 64, 64, 32, 2, 2, 4>(p, s) : launch_cfg<false, 64, 64, 32, 2, 2, 4>(p, s);       // 20 KB LDS: 8 workgroups / CU
+        case 8: return h ? launch_cfg<true, 128, 128, 32, 2, 2, 4>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2, 4>(p, s);
         case 9: return h ? launch_cfg<true, 256, 128, 32, 4, 2>(p, s) : launch_cfg<false, 256, 128, 32, 4, 2>(p, s);             // 8 waves: operand bytes per MFMA -25 %
         case 10: return h ? launch_cfg<true, 256, 256, 32, 4, 2>(p, s) : launch_cfg<false, 256, 256, 32, 4, 2>(p, s);            // 8 waves, 64x128 per wave: -50 %
         case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
