@@ -12,6 +12,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is many small fp32 ops: on the GPU box's 100+ host cores torch's default thread count makes every one of
+    # them slower (the same effect bench.py's cpu_baseline measured: 335 s vs 7 s per DDIM step) -- and the GPU sits idle meanwhile.
+    import torch
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
 
 
 @pytest.fixture(scope="session")
