@@ -214,6 +214,8 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int k0 = 0; k0 < 2; k0 += KB) {
+            // a block that lies entirely past the last key (77 text tokens: keys 96..127 of the second tile) contributes nothing
+            if (t * KT + k0 * 32 >= L) continue;
             // ---- S^T = K Q^T: every K fragment is read from LDS once and used for all QW query blocks ----
             f32x16 s[QW][KB];
 #pragma unroll
