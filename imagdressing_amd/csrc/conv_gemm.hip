@@ -334,6 +334,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 6: *bm = 64; *bn = 320; return 0;
         case 9: *bm = 256; *bn = 128; return 0;
         case 10: *bm = 256; *bn = 256; return 0;
+        case 11: *bm = 128; *bn = 320; return 0;
         default: return 1;
     }
 }
@@ -426,6 +427,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 8: return h ? launch_cfg<true, 128, 128, 32, 2, 2, 4>(p, s) : launch_cfg<false, 128, 128, 32, 2, 2, 4>(p, s);
         case 9: return h ? launch_cfg<true, 256, 128, 32, 4, 2>(p, s) : launch_cfg<false, 256, 128, 32, 4, 2>(p, s);             // 8 waves: operand bytes per MFMA -25 %
         case 10: return h ? launch_cfg<true, 256, 256, 32, 4, 2>(p, s) : launch_cfg<false, 256, 256, 32, 4, 2>(p, s);            // 8 waves, 64x128 per wave: -50 %
+        case 11: return h ? launch_cfg<true, 128, 320, 64, 4, 2>(p, s) : launch_cfg<false, 128, 320, 64, 4, 2>(p, s);            // N = 320 k: one full-width row block per CU
         case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
             int rc = imd_launch_conv_patch(p, s);
             if (rc || p.split_k <= 1) return rc;

@@ -132,8 +132,8 @@ int imd_device_check(int device);
  * RefSAttnProcessor2_0.to_k_ref/to_v_ref (adapter/attention_processor.py:600-601), to_k_ip/to_v_ip (:841-842),
  * the nn.Linear layers of adapter/resampler.py.  cfg (rows x channels x K-depth of a workgroup tile): -1 auto, 0: 128x128x64, 1: 128x64x64, 2: 64x64x64,
  * 3: 64x64x64 with 4 K tiles in flight, 4: 128x128x32, 5: 3x3 halo-patch kernel, 6: 64x320x32 (N % 320 == 0: no idle columns),
- * 7: 64x64x32 / 4 in flight, 8: 128x128x32 / 4 in flight, 9: 256x128x32 and 10: 256x256x32 (8-wave workgroups: fewer operand
- * bytes fetched per MFMA for the wide projections).  Results are identical up to fp32 summation order. */
+ * 7: 64x64x32 / 4 in flight, 8: 128x128x32 / 4 in flight, 9: 256x128x32, 10: 256x256x32 and 11: 128x320x64 (8-wave workgroups:
+ * fewer operand bytes fetched per MFMA for the wide projections; 11 covers N = 320 k with full-width row blocks).  Results are identical up to fp32 summation order. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);
 /* suggested number of K slices for tile config `cfg` (1 = do not split) */

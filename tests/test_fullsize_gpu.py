@@ -231,7 +231,7 @@ def test_full_linear_tile_configs_agree(ops, M, N, K):
     ref = (x[:256].float() @ w.float().t() + b)
     assert (base[:256] - ref).abs().max() < 1e-2 + 1e-2 * ref.abs().max()
     tol = 2 ** -7 * max(1.0, base.abs().max().item()) * 1.01
-    for cfg in (1, 2, 3, 4, 6, 7, 8, 9, 10, -1):
+    for cfg in (1, 2, 3, 4, 6, 7, 8, 9, 10, 11, -1):
         got = ops.linear(x, w, b, cfg=cfg, split_k=(0 if cfg == -1 else 1)).float()
         assert (got - base).abs().max() <= tol, (cfg, (got - base).abs().max().item())
 

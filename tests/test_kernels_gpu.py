@@ -52,7 +52,7 @@ def assert_close(got, ref, atol=None, rtol=None, what=""):
 # ------------------------------------------------------------------------------------------
 # linear / GEMM
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, -1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, -1])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 320, 320), (77, 64, 768), (8, 1280, 320), (130, 4, 72)])
 @DTS
 def test_linear(ops, cfg, M, N, K, dt):
@@ -121,7 +121,7 @@ def pack_conv(w):  # [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
     (2, 16, 16, 64, 64, 1, False), (1, 12, 20, 32, 320, 1, False), (2, 16, 16, 64, 128, 2, False),
     (1, 8, 8, 64, 64, 1, True), (1, 9, 7, 8, 320, 1, False), (3, 6, 6, 320, 4, 1, False)])
