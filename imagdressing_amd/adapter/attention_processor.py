@@ -93,6 +93,51 @@ class _TensorCache:
         return value
 
 
+_W_PARTS = {"qkv": ("to_q", "to_k", "to_v"), "kv": ("to_k", "to_v"), "q": ("to_q",), "o": ("to_out",), "bo": ("to_out",)}
+_16BIT = (torch.bfloat16, torch.float16)
+
+
+def _compute_dtype(attn, hidden_states: torch.Tensor, attention_mask=None):
+    """Also the one place that refuses the module options the reference processors honour
+    (attention_processor.py:545-566, :619-625) but SD1.5 never sets -- refusing beats silently diverging.
+
+    16-bit element type a layer runs in: that of its projection weights (the engines' own ``Attention`` and a
+    diffusers ``Attention`` after ``.to(dtype=torch.float16)``, inference_IMAGdressing.py:50-52), else that of the
+    activations, else fp16 (the reference's GPU dtype)."""
+    if attention_mask is not None:
+        raise NotImplementedError("attention_mask is always None on the IMAGDressing path (SURVEY appendix 3); masks are not implemented")
+    if getattr(attn, "spatial_norm", None) is not None or getattr(attn, "group_norm", None) is not None \
+            or getattr(attn, "norm_cross", None):
+        raise NotImplementedError("attn.spatial_norm / group_norm / norm_cross are None for every SD1.5 attention layer; "
+                                  "modules that set them are not supported by the fused processors")
+    wd = attn.to_q.weight.dtype
+    if wd in _16BIT:
+        return wd
+    return hidden_states.dtype if hidden_states.dtype in _16BIT else torch.float16
+
+
+def _layer_weights(attn, which: str, dtype, device) -> torch.Tensor:
+    """Projection weights of ``attn`` read ONLY through the attribute surface a diffusers ``Attention`` has
+    (attention_processor.py:545-625: ``to_q`` / ``to_k`` / ``to_v`` / ``to_out[0]``): 'qkv' [3C, C] and 'kv' [2C, Kd] are
+    concatenated once, 'q' / 'o' are passed through (cast once if the module is not 16-bit / not on the device), 'bo' is
+    the out-projection bias as fp32 (or None).  Cached on the module, keyed by the identity and version of the source
+    parameters, so ``load_state_dict`` / ``.to()`` / in-place edits rebuild it."""
+    mods = [attn.to_out[0] if n == "to_out" else getattr(attn, n) for n in _W_PARTS[which]]
+    srcs = [m.bias if which == "bo" else m.weight for m in mods]
+    if srcs[0] is None:
+        return None
+    want = torch.float32 if which == "bo" else dtype
+    if len(srcs) == 1 and srcs[0].dtype == want and srcs[0].device == device and srcs[0].is_contiguous():
+        return srcs[0].detach()
+    cache = attn.__dict__.setdefault("_imd_wcache", {})
+    key = (_version_key(*srcs), want, str(device))
+    ent = cache.get(which)
+    if ent is None or ent[0] != key or not all(a is b for a, b in zip(ent[1], srcs)):
+        t = torch.cat([t.detach().to(device=device, dtype=want) for t in srcs], 0).contiguous()
+        ent = cache[which] = (key, tuple(srcs), t)
+    return ent[2]
+
+
 def _as_tokens(hidden_states: torch.Tensor, dtype):
     """Accept [B, N, C] (transformer blocks) or [B, C, H, W] (attention_processor.py:548-552); cast to the
     16-bit element type of the layer's packed weights (bf16 or fp16)."""
@@ -173,37 +218,43 @@ class _FusedBase:
     def _finish(attn, out, residual_given, like, shape4):
         # attn.residual_connection / rescale_output_factor are False / 1.0 for SD1.5 (:622-625)
         if getattr(attn, "residual_connection", False) and not residual_given:
-            out = ops.add(out, like)
+            out = ops.add(out, _as_tokens(like, out.dtype)[0])
         if getattr(attn, "rescale_output_factor", 1.0) != 1.0:
             raise NotImplementedError("rescale_output_factor != 1 is not used by SD1.5")
-        return _restore(out, shape4, like)
+        out = _restore(out, shape4, like)
+        # same dtype as ``hidden_states`` (the processor protocol); a no-op inside the engines
+        return out if out.dtype == like.dtype else out.to(like.dtype)
 
 
 class AttnProcessor2_0(_FusedBase):
     """Plain attention (diffusers' default processor; what a ControlNet / un-patched UNet runs)."""
 
-    def __init__(self):
+    def __init__(self, cache_entries: int = 256):
         # ONE instance may serve every attention layer of a model (``set_attn_processor(proc)``, as diffusers
-        # does): cached K/V are keyed by the conditioning tensor AND the layer's own projection weights.
-        self._text = _TensorCache(capacity=256)
+        # does): cached K/V are keyed by the conditioning tensor AND the layer's own projection weights, hence the
+        # default of 256 entries.  Processors that embed a private instance per layer pass a handful (cond / uncond
+        # alternation) so that a long-running process does not pin stale text K/V of every past call.
+        self._text = _TensorCache(capacity=cache_entries)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  imd_residual=None, **kwargs):
-        x, shape4 = _as_tokens(hidden_states, attn.to_q.weight.dtype)
-        wo, bo = attn.to_out[0].weight, attn.to_out[0].bias
+        dt = _compute_dtype(attn, hidden_states, attention_mask)
+        x, shape4 = _as_tokens(hidden_states, dt)
+        dev = x.device
+        wo, bo = _layer_weights(attn, "o", dt, dev), _layer_weights(attn, "bo", dt, dev)
         if encoder_hidden_states is None:
-            out = _fused_attention(x, attn.heads, wq_or_qkv=attn.packed("qkv"), self_attn=True, wo=wo, bo=bo,
+            out = _fused_attention(x, attn.heads, wq_or_qkv=_layer_weights(attn, "qkv", dt, dev), self_attn=True, wo=wo, bo=bo,
                                    residual=imd_residual)
         else:
             srcs = (encoder_hidden_states, attn.to_k.weight, attn.to_v.weight)
-            kv = self._text.get(srcs)
+            kv = self._text.get(srcs, extra=(dt,))
             if kv is None:
-                e = encoder_hidden_states.to(device=x.device, dtype=x.dtype).contiguous()
-                kv = self._text.put(srcs, _project_kv(e, attn.packed("kv"), attn.heads))
-            out = _fused_attention(x, attn.heads, wq_or_qkv=attn.to_q.weight, self_attn=False, kv1=kv,
+                e = encoder_hidden_states.to(device=dev, dtype=dt).contiguous()
+                kv = self._text.put(srcs, _project_kv(e, _layer_weights(attn, "kv", dt, dev), attn.heads), extra=(dt,))
+            out = _fused_attention(x, attn.heads, wq_or_qkv=_layer_weights(attn, "q", dt, dev), self_attn=False, kv1=kv,
                                    kv1_bdiv=self._ehs_bdiv(x.shape[0], encoder_hidden_states), wo=wo, bo=bo,
                                    residual=imd_residual)
-        return self._finish(attn, out, imd_residual is not None, x, shape4)
+        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
 
 
 class CacheAttnProcessor2_0(AttnProcessor2_0):
@@ -245,9 +296,18 @@ class _RefMixin:
                                    extra=(dtype,))
             r = ref.detach().to(device=device, dtype=dtype).contiguous()
             if r.dim() != 3:
-                raise ValueError(f"sa_hidden_states[{self.name!r}] must be [1, M, C], got {tuple(ref.shape)}")
+                raise ValueError(f"sa_hidden_states[{self.name!r}] must be [Bg, M, C], got {tuple(ref.shape)}")
             kv = self._garment.put((ref,) + wsrc, _project_kv(r, w, heads), extra=(dtype,))
         return kv
+
+    def _garment_bdiv(self, B: int, ref: torch.Tensor) -> int:
+        """Batch rows per garment: [1, M, C] is shared by the whole batch; [Bg, M, C] (the reference's own
+        ``view(batch_size, ...)`` layout at :602-603, or several garments in one call) serves contiguous groups of
+        B / Bg rows.  Anything else would silently pair rows with the wrong garment, so it raises."""
+        Bg = ref.shape[0]
+        if Bg < 1 or B % Bg:
+            raise ValueError(f"sa_hidden_states[{self.name!r}] has batch {Bg}, which does not divide hidden_states batch {B}")
+        return B // Bg
 
     def _branch_weights(self, B: int, mask: Optional[torch.Tensor], device) -> torch.Tensor:
         """[B] fp32 = scale (* sa_batch_mask)."""
@@ -272,23 +332,27 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
         super().__init__()
         self._init_ref(name, hidden_size, cross_attention_dim, scale)
 
-    def _weights(self, attn):
-        return attn.packed("qkv"), attn.to_out[0].weight, attn.to_out[0].bias
+    def _weights(self, attn, dt, dev):
+        return _layer_weights(attn, "qkv", dt, dev), _layer_weights(attn, "o", dt, dev), _layer_weights(attn, "bo", dt, dev)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  num_images_per_prompt=1, cond_hidden_states=None, sa_hidden_states=None, sa_batch_mask=None,
                  imd_residual=None, **kwargs):
         if encoder_hidden_states is not None:
             raise NotImplementedError(f"{type(self).__name__} is a self-attention (attn1) processor")
-        x, shape4 = _as_tokens(hidden_states, attn.to_q.weight.dtype)
-        wqkv, wo, bo = self._weights(attn)
+        dt = _compute_dtype(attn, hidden_states, attention_mask)
+        x, shape4 = _as_tokens(hidden_states, dt)
+        wqkv, wo, bo = self._weights(attn, dt, x.device)
         kv2 = s2 = None
+        bdiv2 = 1
         if sa_hidden_states is not None:                                   # :597
-            kv2 = self._garment_kv(sa_hidden_states[self.name], attn.heads, x.device, x.dtype)
+            ref = sa_hidden_states[self.name]
+            kv2 = self._garment_kv(ref, attn.heads, x.device, x.dtype)
+            bdiv2 = self._garment_bdiv(x.shape[0], ref)
             s2 = self._branch_weights(x.shape[0], sa_batch_mask, x.device)
-        out = _fused_attention(x, attn.heads, wq_or_qkv=wqkv, self_attn=True, kv2=kv2, kv2_bdiv=max(x.shape[0], 1),
+        out = _fused_attention(x, attn.heads, wq_or_qkv=wqkv, self_attn=True, kv2=kv2, kv2_bdiv=bdiv2,
                                scale2=s2, wo=wo, bo=bo, residual=imd_residual)
-        return self._finish(attn, out, imd_residual is not None, x, shape4)
+        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
 
 
 class _LoraFold:
@@ -303,21 +367,22 @@ class _LoraFold:
         self.to_out_lora = LoRALinearLayer(hidden_size, hidden_size, rank, network_alpha)
         self._folded = _TensorCache()
 
-    def _fold(self, attn, device):
+    def _fold(self, attn, device, dtype):
         ls = float(self.lora_scale)
         srcs = tuple(l.weight for lo in (self.to_q_lora, self.to_k_lora, self.to_v_lora, self.to_out_lora)
                      for l in (lo.down, lo.up)) + (attn.to_q.weight, attn.to_k.weight, attn.to_v.weight, attn.to_out[0].weight)
-        w = self._folded.get(srcs, extra=(ls,))
+        w = self._folded.get(srcs, extra=(ls, dtype, str(device)))
         if w is None:
             def eff(base, lora):
+                base = base.detach().to(device)
                 if ls == 0.0:
-                    return base
-                return (base.float() + ls * lora.delta().to(device)).to(base.dtype).contiguous()
+                    return base.to(dtype).contiguous()
+                return (base.float() + ls * lora.delta().to(device)).to(dtype).contiguous()
             wq, wk, wv = eff(attn.to_q.weight, self.to_q_lora), eff(attn.to_k.weight, self.to_k_lora), eff(attn.to_v.weight, self.to_v_lora)
             wo = eff(attn.to_out[0].weight, self.to_out_lora)
             w = self._folded.put(srcs, dict(q=wq, kv=torch.cat([wk, wv], 0).contiguous(),
                                             qkv=(torch.cat([wq, wk, wv], 0).contiguous() if wk.shape[1] == wq.shape[1] else None),
-                                            o=wo), extra=(ls,))
+                                            o=wo), extra=(ls, dtype, str(device)))
         return w
 
 
@@ -331,9 +396,9 @@ class _LoraRefSBase(nn.Module, _FusedBase, _RefMixin, _LoraFold):
         self._init_ref(name, hidden_size, cross_attention_dim, scale)
         self._init_lora(hidden_size, cross_attention_dim or hidden_size, rank, network_alpha, lora_scale)
 
-    def _weights(self, attn):
-        w = self._fold(attn, attn.to_q.weight.device)
-        return w["qkv"], w["o"], attn.to_out[0].bias
+    def _weights(self, attn, dt, dev):
+        w = self._fold(attn, dev, dt)
+        return w["qkv"], w["o"], _layer_weights(attn, "bo", dt, dev)
 
     __call__ = RefSAttnProcessor2_0.__call__
 
@@ -355,7 +420,7 @@ class CAttnProcessor2_0(nn.Module, _FusedBase):
         self.name = name
         self.hidden_size = hidden_size
         self.cross_attention_dim = cross_attention_dim
-        self._plain = AttnProcessor2_0()
+        self._plain = AttnProcessor2_0(cache_entries=4)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  cond_hidden_states=None, sa_hidden_states=None, imd_residual=None, **kwargs):
@@ -380,16 +445,17 @@ class _IPBase(nn.Module, _FusedBase, _LoraFold):
         self._wip = _TensorCache()
         self._s2: Dict = {}
 
-    def _weights(self, attn):
-        w = self._fold(attn, attn.to_q.weight.device)
+    def _weights(self, attn, dt, dev):
+        w = self._fold(attn, dev, dt)
         return w["q"], w["kv"], w["o"]
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, scale=1.0, temb=None,
                  *args, imd_residual=None, **kwargs):
         if encoder_hidden_states is None:
             raise NotImplementedError(f"{type(self).__name__} is a cross-attention (attn2) processor")
-        x, shape4 = _as_tokens(hidden_states, attn.to_q.weight.dtype)
-        wq, wkv, wo = self._weights(attn)
+        dt = _compute_dtype(attn, hidden_states, attention_mask)
+        x, shape4 = _as_tokens(hidden_states, dt)
+        wq, wkv, wo = self._weights(attn, dt, x.device)
         wsrc = (self.to_k_ip.weight, self.to_v_ip.weight)
         ls = float(getattr(self, "lora_scale", 0.0))
         ksrc = (encoder_hidden_states, attn.to_k.weight, attn.to_v.weight) + wsrc
@@ -412,8 +478,8 @@ class _IPBase(nn.Module, _FusedBase, _LoraFold):
             self._s2 = {key: s2}
         bdiv = self._ehs_bdiv(B, encoder_hidden_states)
         out = _fused_attention(x, attn.heads, wq_or_qkv=wq, self_attn=False, kv1=kvs[0], kv1_bdiv=bdiv, kv2=kvs[1],
-                               kv2_bdiv=bdiv, scale2=s2, wo=wo, bo=attn.to_out[0].bias, residual=imd_residual)
-        return self._finish(attn, out, imd_residual is not None, x, shape4)
+                               kv2_bdiv=bdiv, scale2=s2, wo=wo, bo=_layer_weights(attn, "bo", dt, x.device), residual=imd_residual)
+        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
 
 
 class LoRAIPAttnProcessor2_0(_IPBase):
@@ -436,8 +502,8 @@ class IPAttnProcessor2_0(_IPBase):
         self._wip = _TensorCache()
         self._s2 = {}
 
-    def _weights(self, attn):
-        return attn.to_q.weight, attn.packed("kv"), attn.to_out[0].weight
+    def _weights(self, attn, dt, dev):
+        return _layer_weights(attn, "q", dt, dev), _layer_weights(attn, "kv", dt, dev), _layer_weights(attn, "o", dt, dev)
 
 
 # ---- legacy names: defined by the reference but used by none of its entry points ----------------
@@ -447,7 +513,7 @@ class BaseSAttnProcessor2_0(nn.Module, _FusedBase):
     def __init__(self, name, cross_attention_dim=None):
         super().__init__()
         self.name, self.cross_attention_dim = name, cross_attention_dim
-        self._plain = AttnProcessor2_0()
+        self._plain = AttnProcessor2_0(cache_entries=4)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  imd_residual=None, **kwargs):
@@ -462,7 +528,7 @@ class SAttnProcessor2_0(nn.Module, _FusedBase):
     def __init__(self, name, hidden_size, cross_attention_dim=None):
         super().__init__()
         self.name, self.hidden_size, self.cross_attention_dim = name, hidden_size, cross_attention_dim
-        self._plain = AttnProcessor2_0()
+        self._plain = AttnProcessor2_0(cache_entries=4)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  sa_hidden_states=None, imd_residual=None, **kwargs):
@@ -483,7 +549,7 @@ class RefCAttnProcessor2_0(nn.Module, _FusedBase):
         self.to_k_ref = nn.Linear(hidden_size, hidden_size, bias=False)
         self.to_v_ref = nn.Linear(hidden_size, hidden_size, bias=False)
         self.scale = scale
-        self._plain = AttnProcessor2_0()
+        self._plain = AttnProcessor2_0(cache_entries=4)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  cond_hidden_states=None, sa_hidden_states=None, imd_residual=None, **kwargs):

@@ -25,6 +25,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .hub import PretrainedMixin
 from .unet import LinearOp, NormParams
 
 bf16 = torch.bfloat16
@@ -73,8 +74,11 @@ class _Layer:
         return self.fc2(x, res=h).view(B, N, Cc)
 
 
-class CLIPTextModel:
+class CLIPTextModel(PretrainedMixin):
     """`transformers.CLIPTextModel` surface used by the pipelines: `model(input_ids)[0]` = last_hidden_state [B, T, C]."""
+
+    _config_keys = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+                    "max_position_embeddings", "hidden_act", "layer_norm_eps")
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[dict] = None, device="cuda", dtype=bf16):
         device = torch.device(device)
@@ -82,6 +86,7 @@ class CLIPTextModel:
         cfg = dict(TEXT_CONFIG, **(config or {}))
         sd = _strip(state_dict, "text_model.")
         self.cfg, self.config = cfg, types.SimpleNamespace(**cfg)
+        self._ctor_config = config
         self.device, self.dtype = device, dtype
         self.tok = sd["embeddings.token_embedding.weight"].detach().to(device=device, dtype=dtype).contiguous()
         self.pos = sd["embeddings.position_embedding.weight"].detach().to(device=device, dtype=dtype).contiguous()
@@ -92,12 +97,6 @@ class CLIPTextModel:
 
     def parameters(self):
         yield self.tok
-
-    def to(self, *a, **k):
-        return self
-
-    def eval(self):
-        return self
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, attention_mask=None, output_hidden_states: bool = False, **unused):
@@ -120,8 +119,11 @@ class CLIPTextModel:
         return out
 
 
-class CLIPVisionModelWithProjection:
+class CLIPVisionModelWithProjection(PretrainedMixin):
     """`transformers.CLIPVisionModelWithProjection` surface used by the pipelines: `.hidden_states[-2]`, `.image_embeds`."""
+
+    _config_keys = ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "image_size",
+                    "patch_size", "projection_dim", "hidden_act", "layer_norm_eps")
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[dict] = None, device="cuda", dtype=bf16):
         device = torch.device(device)
@@ -130,6 +132,7 @@ class CLIPVisionModelWithProjection:
         proj_w = state_dict["visual_projection.weight"]
         sd = _strip(state_dict, "vision_model.")
         self.cfg, self.config = cfg, types.SimpleNamespace(**cfg)
+        self._ctor_config = config
         self.device, self.dtype = device, dtype
         Cc, ps, nc = cfg["hidden_size"], cfg["patch_size"], cfg["num_channels"]
         self.kdim = nc * ps * ps
@@ -148,12 +151,6 @@ class CLIPVisionModelWithProjection:
 
     def parameters(self):
         yield self.cls
-
-    def to(self, *a, **k):
-        return self
-
-    def eval(self):
-        return self
 
     @torch.no_grad()
     def __call__(self, pixel_values: torch.Tensor, output_hidden_states: bool = False, **unused):

@@ -1,0 +1,128 @@
+"""``from_pretrained`` for the MI355X engines: the model-construction lines of the reference's ``prepare()``
+(/root/reference/inference_IMAGdressing.py:42-52, :90-92; ..._ipa_controlnetpose.py / ..._controlnetinpainting.py likewise)
+keep their shape --
+
+    unet = UNet2DConditionModel.from_pretrained(path, subfolder="unet").to(dtype=torch.float16, device=args.device)
+
+-- with the class imported from ``imagdressing_amd`` instead of ``diffusers`` / ``transformers``.  Only LOCAL directories in
+the Hugging Face layout are read (``<path>/<subfolder>/config.json`` + ``diffusion_pytorch_model.safetensors`` |
+``model.safetensors`` | ``*.bin``); there is no hub client here.  ``from_pretrained`` returns a light handle holding the
+CPU state dict; ``.to(dtype=, device=)`` is where the engine is built (weights are repacked once for the kernels and land in
+HBM -- there is no CPU engine to move from), so the script's chained ``.to(...)`` costs nothing extra.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+WEIGHT_FILES = ("diffusion_pytorch_model.safetensors", "model.safetensors", "diffusion_pytorch_model.fp16.safetensors",
+                "diffusion_pytorch_model.bin", "pytorch_model.bin")
+
+
+def read_pretrained_dir(path: str, subfolder: Optional[str] = None):
+    """-> (state dict on the CPU, config dict) of a local Hugging Face model directory."""
+    d = os.path.join(path, subfolder) if subfolder else path
+    if not os.path.isdir(d):
+        raise FileNotFoundError(f"from_pretrained: {d!r} is not a local directory (this build has no hub access; "
+                                "download the model and pass its path)")
+    cfg = {}
+    cj = os.path.join(d, "config.json")
+    if os.path.isfile(cj):
+        with open(cj) as f:
+            cfg = json.load(f)
+    for name in WEIGHT_FILES:
+        f = os.path.join(d, name)
+        if os.path.isfile(f):
+            from .checkpoint import load_state_dict_file
+            return load_state_dict_file(f), cfg
+    raise FileNotFoundError(f"from_pretrained: none of {WEIGHT_FILES} found in {d!r}")
+
+
+class PendingModel:
+    """What ``Engine.from_pretrained`` returns: ``.to(dtype=, device=)`` (or any positional mix torch accepts) builds the
+    engine.  ``.config`` is available before that (the reference reads ``unet.config.cross_attention_dim`` only after
+    ``.to``, but nothing forbids the other order)."""
+
+    def __init__(self, cls, state_dict: Dict[str, torch.Tensor], config: dict, engine_config: Optional[dict]):
+        self._cls, self._sd, self._engine_config = cls, state_dict, engine_config
+        from types import SimpleNamespace
+        self.config = SimpleNamespace(**config)
+
+    def to(self, *args, dtype=None, device=None, **unused):
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif isinstance(a, (str, torch.device, int)):
+                device = a
+        if dtype is None:
+            dtype = torch.float16                 # the reference's dtype (inference_IMAGdressing.py:42-52)
+        if device is None:
+            device = "cuda"
+        eng = self._cls(self._sd, self._engine_config, device, dtype)
+        self._sd = None
+        return eng
+
+    def __getattr__(self, name):
+        raise AttributeError(f"{self._cls.__name__}.from_pretrained(...) handle has no attribute {name!r}: call "
+                             ".to(dtype=..., device=...) first (that is where the MI355X engine is built)")
+
+
+class PretrainedMixin:
+    """``from_pretrained`` / ``load_state_dict`` / ``state_dict`` / ``to`` / ``eval`` / ``requires_grad_`` for an engine whose
+    constructor is ``cls(state_dict, config, device, dtype)``."""
+
+    #: config.json keys that map onto the engine's config dict (everything else is the fixed SD1.5 architecture)
+    _config_keys = ()
+
+    @classmethod
+    def _engine_config(cls, hf_config: dict) -> Optional[dict]:
+        out = {}
+        for k in cls._config_keys:
+            if k in hf_config and hf_config[k] is not None:
+                v = hf_config[k]
+                out[k] = tuple(v) if isinstance(v, list) else v
+        return out or None
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder: Optional[str] = None, torch_dtype=None, **unused):
+        sd, cfg = read_pretrained_dir(str(pretrained_model_name_or_path), subfolder)
+        pend = PendingModel(cls, sd, cfg, cls._engine_config(cfg))
+        return pend if torch_dtype is None else pend.to(dtype=torch_dtype)
+
+    def to(self, *args, dtype=None, device=None, **unused):
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            elif isinstance(a, (str, torch.device, int)):
+                device = a
+        if dtype is not None and dtype != self.dtype:
+            raise ValueError(f"{type(self).__name__} was built as {self.dtype}; engines are not re-cast (weights are repacked "
+                             f"for the kernels at build time) -- build it with dtype={dtype}")
+        if device is not None and torch.device(device).type != "cuda":
+            raise ValueError(f"{type(self).__name__} runs on MI355X only; cannot move to {device}")
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def state_dict(self):
+        """The engines keep weights REPACKED (NHWC filters, interleaved GEGLU rows, fused time-embedding projection, 16-bit),
+        not in the diffusers layout, so there is nothing meaningful to hand back; the reference only takes and deletes this
+        (inference_IMAGdressing.py:68,88)."""
+        return {}
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """Rebuild the engine in place from a diffusers-layout state dict (``ref_unet.load_state_dict(ref_unet_dict)``,
+        inference_IMAGdressing.py:114); installed attention processors are kept."""
+        procs = dict(self.attn_processors) if hasattr(self, "attn_processors") else None
+        cfg = getattr(self, "_ctor_config", None)
+        self.__init__(state_dict, cfg, self.device, self.dtype)
+        if procs is not None:
+            self.set_attn_processor(procs)
+        return torch.nn.modules.module._IncompatibleKeys([], [])

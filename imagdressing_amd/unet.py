@@ -29,6 +29,7 @@ from typing import Dict, List, Optional
 import torch
 
 from . import ops
+from .hub import PretrainedMixin
 
 bf16 = torch.bfloat16
 
@@ -233,22 +234,12 @@ class Attention:
         self.residual_connection = False
         self.rescale_output_factor = 1.0
         self.processor = None
-        self._packed: Dict[str, torch.Tensor] = {}
 
     def prepare_attention_mask(self, mask, *a, **k):
         return mask
 
     def set_processor(self, p):
         self.processor = p
-
-    def packed(self, which: str) -> torch.Tensor:
-        """Concatenated projection weights ('qkv' [3C, C] or 'kv' [2C, Kd]) built once."""
-        t = self._packed.get(which)
-        if t is None:
-            parts = {"qkv": (self.to_q, self.to_k, self.to_v), "kv": (self.to_k, self.to_v)}[which]
-            t = torch.cat([p.weight for p in parts], dim=0).contiguous()
-            self._packed[which] = t
-        return t
 
     def __call__(self, hidden_states, encoder_hidden_states=None, residual=None, **cross_attention_kwargs):
         proc = self.processor
@@ -326,8 +317,10 @@ class ResnetBlock:
         return self.conv2(h, res=sc)
 
 
-class _Encoder:
+class _Encoder(PretrainedMixin):
     """conv_in + time embedding + down blocks + mid block (shared by the UNet and the ControlNet)."""
+    _config_keys = ("in_channels", "out_channels", "block_out_channels", "layers_per_block", "attention_head_dim",
+                    "cross_attention_dim", "norm_num_groups", "sample_size")
 
     def _build_encoder(self, sd, cfg, device):
         boc = cfg["block_out_channels"]
@@ -443,6 +436,7 @@ class UNet2DConditionModel(_Encoder):
             if tuple(state_dict[k].shape) != shp:
                 raise ValueError(f"{k}: shape {tuple(state_dict[k].shape)} != expected {shp}")
         self.cfg = cfg
+        self._ctor_config = config
         self.config = SimpleNamespace(**cfg)
         self.device = torch.device(device)
         self.dtype = dtype
@@ -546,6 +540,7 @@ class ControlNetModel(_Encoder):
         if missing:
             raise KeyError(f"ControlNet state dict is missing {len(missing)} keys, e.g. {missing[0]}")
         self.cfg = cfg
+        self._ctor_config = config
         self.config = SimpleNamespace(global_pool_conditions=False, **cfg)
         self.device = torch.device(device)
         self.dtype = dtype

@@ -23,6 +23,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .hub import PretrainedMixin
 from .unet import ConvOp, LinearOp, NormParams, nchw_to_nhwc8
 
 bf16 = torch.bfloat16
@@ -161,12 +162,15 @@ class DiagonalGaussian:
         return self.mean + self.std * noise
 
 
-class AutoencoderKL:
+class AutoencoderKL(PretrainedMixin):
+    _config_keys = ("block_out_channels", "layers_per_block", "latent_channels", "norm_num_groups", "scaling_factor")
+
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[dict] = None, device="cuda", dtype=bf16):
         device = torch.device(device)
         ops.ensure_device(device)
         cfg = dict(VAE_CONFIG, **(config or {}))
         self.cfg = cfg
+        self._ctor_config = config
         self.config = types.SimpleNamespace(**cfg)
         self.device, self.dtype = device, dtype
         sd = state_dict
@@ -231,12 +235,6 @@ class AutoencoderKL:
 
     def disable_slicing(self):
         self.use_slicing = False
-
-    def to(self, *a, **k):
-        return self
-
-    def eval(self):
-        return self
 
     # ---- compute ------------------------------------------------------------------------------------------------
     def encode_nhwc(self, x8: torch.Tensor) -> torch.Tensor:

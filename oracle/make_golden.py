@@ -2,7 +2,7 @@
 (``/root/reference/adapter/attention_processor.py`` and ``adapter/resampler.py``, imported
 verbatim through ``oracle/ref_loader.py``) on seeded fp32 inputs (TEST INFRASTRUCTURE).
 
-Run in the build container only:   python -m oracle.make_golden
+Run in the build container only:   python -m oracle.make_golden [base|full|all]
 The fixtures pin ``oracle/processors.py`` and ``oracle/resampler.py`` (tests/test_oracle_golden.py)
 and are what the ``-m gpu`` parity tests compare the HIP path with when /root/reference is absent.
 
@@ -78,12 +78,24 @@ def set_lora(proc, lw):
             layer.down.weight.copy_(lw[nm][0]); layer.up.weight.copy_(lw[nm][1])
 
 
+def spike_tokens(x, ref, spike):
+    """``spike`` = (query token, key token, garment token, factor): scale those rows of x / ref so that, late in the key
+    sequence, some scores jump far above everything seen before (the online-softmax rescale / redo paths of the kernel)."""
+    if spike:
+        qt, kt, gt, f = spike
+        x[:, qt] *= f
+        x[:, kt] *= f
+        ref[:, gt] *= f
+    return x, ref
+
+
 @torch.no_grad()
-def hybrid_case(ap, seed, B, N, M, C, heads, scale, rank=0, lora_scale=0.0, store_full=True):
+def hybrid_case(ap, seed, B, N, M, C, heads, scale, rank=0, lora_scale=0.0, store_full=True, spike=None, keep_rows=0):
     w = attn_weights(seed, C, C)
     attn = make_attn(w, C, C, heads)
     x = seeded(seed + 20, B, N, C)
     ref = seeded(seed + 21, 1, M, C)
+    x, ref = spike_tokens(x, ref, spike)
     wkr, wvr = seeded(seed + 22, C, C, scale=C ** -0.5), seeded(seed + 23, C, C, scale=C ** -0.5)
     name = "blk.attn1.processor"
     if rank:
@@ -97,8 +109,16 @@ def hybrid_case(ap, seed, B, N, M, C, heads, scale, rank=0, lora_scale=0.0, stor
     # the reference is only defined for B == 1 with a 1-batch garment (:602-603): run per sample
     cond = torch.cat([proc(attn, x[b:b + 1], sa_hidden_states={name: ref}) for b in range(B)])
     uncond = torch.cat([proc(attn, x[b:b + 1]) for b in range(B)])
+    rows = None
+    if keep_rows:            # full-size cases keep a seeded subset of the N output rows (plus the spiked ones)
+        import numpy as np
+        rows = np.sort(np.random.default_rng(seed + 99).choice(N, keep_rows, replace=False))
+        if spike:
+            rows = np.unique(np.concatenate([rows, [spike[0], spike[1]]]))
+        rows = torch.from_numpy(rows)
+        cond, uncond = cond[:, rows].clone(), uncond[:, rows].clone()
     case = dict(kind="hybrid", seed=seed, B=B, N=N, M=M, C=C, heads=heads, scale=scale, rank=rank,
-                lora_scale=lora_scale, out_cond=cond, out_uncond=uncond,
+                lora_scale=lora_scale, out_cond=cond, out_uncond=uncond, spike=spike, rows=rows,
                 digests=dict(x=digest(x), ref=digest(ref), wq=digest(w["wq"]), wkr=digest(wkr)))
     if store_full:
         case.update(x=x, ref=ref, wk_ref=wkr, wv_ref=wvr, lora=lw, **w)
@@ -132,14 +152,21 @@ def cross_case(ap, seed, B, N, T, C, KD, heads, ip_tokens=0, ip_scale=1.0, rank=
 
 
 @torch.no_grad()
-def cache_case(ap, seed, B, N, C, heads):
-    w = attn_weights(seed, C, C)
-    attn = make_attn(w, C, C, heads)
+def cache_case(ap, seed, B, N, C, heads, store_full=True, T=0, KD=0):
+    """``CacheAttnProcessor2_0`` as self-attention (T == 0) or as cross-attention over T context tokens of width KD
+    (the garment UNet's attn2 layers read the 16 resampler tokens, IMAGDressing_v1_pipeline.py:466-470)."""
+    w = attn_weights(seed, C, KD or C)
+    attn = make_attn(w, C, KD or C, heads)
     x = seeded(seed + 20, B, N, C)
+    ehs = seeded(seed + 21, B, T, KD, scale=0.5) if T else None
     proc = ap.CacheAttnProcessor2_0()
-    out = proc(attn, x)
+    out = proc(attn, x, encoder_hidden_states=ehs)
     assert proc.cache["hidden_states"] is x            # stores its input (:34)
-    return dict(kind="cache", seed=seed, B=B, N=N, C=C, heads=heads, x=x, out=out, **w)
+    case = dict(kind="cache", seed=seed, B=B, N=N, C=C, heads=heads, T=T, KD=KD, out=out,
+                digests=dict(x=digest(x), wq=digest(w["wq"])))
+    if store_full:
+        case.update(x=x, ehs=ehs, **w)
+    return case
 
 
 def resampler_sd(seed, dim, depth, dim_head, heads, nq, emb, out, ff_mult=4, prefix=""):
@@ -244,5 +271,28 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
+def main_full():
+    """Second fixture file: the reference source at the BENCHMARKED shape of the fused kernel (BASELINE.json configs[1]
+    level 0: N = M = 4096, C = 320, d = 40 -> the two-query-block instantiation), a ragged N >= 512 case with late score
+    spikes (forces the kernel's deferred-max redo path), and ``CacheAttnProcessor2_0`` at a real head dim."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ap, _ = load_reference_adapter()
+    cases = {
+        "hybrid_d40_n4096": hybrid_case(ap, 2000, B=1, N=4096, M=4096, C=320, heads=8, scale=1.0, store_full=False, keep_rows=384),
+        "hybrid_d40_spike": hybrid_case(ap, 2100, B=1, N=840, M=700, C=320, heads=8, scale=0.9, store_full=False,
+                                        spike=(777, 801, 650, 12.0), keep_rows=256),
+        "cache_d40": cache_case(ap, 2200, B=1, N=200, C=320, heads=8, store_full=False),
+        "cache_d80_cross": cache_case(ap, 2300, B=1, N=144, C=640, heads=8, store_full=False, T=16, KD=768),
+    }
+    torch.save(cases, os.path.join(OUT, "processors_full.pt"))
+    print("processors_full.pt", os.path.getsize(os.path.join(OUT, "processors_full.pt")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"          # base | full | all
+    if what in ("base", "all"):
+        main()
+    if what in ("full", "all"):
+        main_full()

@@ -2,7 +2,7 @@
 same calls ``oracle/make_golden.py`` made) and check the regenerated inputs' digests."""
 import torch
 
-from oracle.make_golden import attn_weights, lora_weights, proj_plus_sd, resampler_sd
+from oracle.make_golden import attn_weights, lora_weights, proj_plus_sd, resampler_sd, spike_tokens
 from oracle.seeds import digest, seeded
 
 
@@ -13,11 +13,23 @@ def hybrid_inputs(c):
     d = attn_weights(s, C, C)
     d["x"] = seeded(s + 20, c["B"], c["N"], C)
     d["ref"] = seeded(s + 21, 1, c["M"], C)
+    d["x"], d["ref"] = spike_tokens(d["x"], d["ref"], c.get("spike"))
     d["wk_ref"] = seeded(s + 22, C, C, scale=C ** -0.5)
     d["wv_ref"] = seeded(s + 23, C, C, scale=C ** -0.5)
     d["lora"] = lora_weights(s, C, C, c["rank"]) if c["rank"] else None
     assert digest(d["x"]) == c["digests"]["x"] and digest(d["ref"]) == c["digests"]["ref"]
     assert digest(d["wq"]) == c["digests"]["wq"] and digest(d["wk_ref"]) == c["digests"]["wkr"]
+    return d
+
+
+def cache_inputs(c):
+    if "x" in c:
+        return {k: c.get(k) for k in ("x", "ehs", "wq", "wk", "wv", "wo", "bo")}
+    s, C = c["seed"], c["C"]
+    d = attn_weights(s, C, c["KD"] or C)
+    d["x"] = seeded(s + 20, c["B"], c["N"], C)
+    d["ehs"] = seeded(s + 21, c["B"], c["T"], c["KD"], scale=0.5) if c["T"] else None
+    assert digest(d["x"]) == c["digests"]["x"] and digest(d["wq"]) == c["digests"]["wq"]
     return d
 
 

@@ -28,3 +28,11 @@ def golden_processors():
 def golden_resampler():
     import torch
     return torch.load(os.path.join(GOLDEN, "resampler.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session")
+def golden_full():
+    """Reference-source outputs at the benchmarked kernel shape (N = M = 4096, d = 40), a spiked ragged case and
+    CacheAttnProcessor2_0 at real head dims (oracle/make_golden.py::main_full)."""
+    import torch
+    return torch.load(os.path.join(GOLDEN, "processors_full.pt"), weights_only=False)

@@ -241,6 +241,161 @@ def test_build_engines_from_imagdressing_checkpoint(tmp_path):
     assert torch.equal(eng["image_proj"](clip), proj.to(device="cuda", dtype=dt)(clip))
 
 
+def _write_hf_dir(d, sd, cfg):
+    import json
+    import os
+
+    from safetensors.torch import save_file
+    os.makedirs(d, exist_ok=True)
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, "diffusion_pytorch_model.safetensors"))
+    with open(os.path.join(d, "config.json"), "w") as f:
+        json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.items()}, f)
+
+
+@torch.no_grad()
+def test_prepare_flow_of_the_reference_script(tmp_path):
+    """The BODY of the reference's ``prepare()`` (/root/reference/inference_IMAGdressing.py:40-135), statement for
+    statement, against the MI355X classes: ``from_pretrained(...).to(dtype=, device=)`` from local Hugging Face-layout
+    directories, the ``attn_procs`` loop, ``unet.set_attn_processor``, ``ModuleList(unet.attn_processors.values())
+    .to(...)``, ``torch.load(ckpt)["module"]`` and its prefix split, the three ``load_state_dict`` calls, the scheduler and
+    the pipeline constructor (safety checker / feature extractor passed as CLASSES, :133-134).  Only the import lines
+    differ from the script.  The pipeline it returns generates the same latents as one assembled directly from the same
+    tensors (bit-identical), and ``set_scale`` reaches the loaded processors."""
+    # --- the imports the script would change (INTEGRATION.md section 1) ---
+    from adapter.attention_processor import CacheAttnProcessor2_0, CAttnProcessor2_0, RefSAttnProcessor2_0
+    from adapter.resampler import Resampler
+    from dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+    from imagdressing_amd import unet as E
+    from imagdressing_amd.scheduler import DDIMScheduler
+    from imagdressing_amd.unet import UNet2DConditionModel
+    from imagdressing_amd.vae import AutoencoderKL
+
+    class StableDiffusionSafetyChecker:      # the script passes these two CLASSES, never instances
+        pass
+
+    class CLIPImageProcessor:
+        pass
+    # --- synthetic "downloads": an SD-layout UNet dir, a VAE dir, and a DeepSpeed-wrapped IMAGDressing checkpoint ---
+    full = dict(E.SD15_CONFIG, **SMALL)
+    sd_u = E.random_state_dict(E.unet_param_shapes(full), 0)
+    sd_r = E.random_state_dict(E.unet_param_shapes(full), 1)
+    _write_hf_dir(tmp_path / "rv" / "unet", sd_u, {k: full[k] for k in ("block_out_channels", "attention_head_dim", "norm_num_groups",
+                                                                        "cross_attention_dim", "in_channels", "out_channels")})
+    from oracle import vae as OV
+    vcfg = dict(block_out_channels=(64, 128, 128, 128), norm_num_groups=8)
+    sd_v = OV.seeded_state_dict(vcfg, seed=0)
+    _write_hf_dir(tmp_path / "vae", sd_v, vcfg)
+    pair = build_pair(SMALL, seed=0, dtype=torch.float16)            # directly-assembled twin (same seeds -> same tensors)
+    rk = dict(dim=64, depth=2, dim_head=64, heads=2, num_queries=16, embedding_dim=96, output_dim=64, ff_mult=2)
+    torch.manual_seed(3)
+    proj0 = Resampler(**rk)
+    ck = {}
+    ck.update({"ref_unet." + k: v for k, v in sd_r.items()})
+    ck.update({"unet." + k: v for k, v in sd_u.items()})
+    ck.update({"proj." + k: v.detach().cpu() for k, v in proj0.state_dict().items()})
+    ck.update({"adapter_modules." + k: v.detach().float().cpu()
+               for k, v in torch.nn.ModuleList(pair["e_unet"].attn_processors.values()).state_dict().items()})
+    torch.save({"module": ck}, tmp_path / "IMAGDressing-v1_small.pt")
+
+    class args:
+        device = "cuda"
+        model_ckpt = str(tmp_path / "IMAGDressing-v1_small.pt")
+
+    # ================= body of prepare(), inference_IMAGdressing.py:41-135 (tokenizer / CLIP encoders left out: the test
+    # feeds embeddings) =================
+    generator = torch.Generator(device="cpu").manual_seed(42)
+    vae = AutoencoderKL.from_pretrained(str(tmp_path / "vae")).to(dtype=torch.float16, device=args.device)
+    unet = UNet2DConditionModel.from_pretrained(str(tmp_path / "rv"), subfolder="unet").to(
+        dtype=torch.float16,
+        device=args.device)
+    image_proj = Resampler(
+        dim=unet.config.cross_attention_dim,
+        depth=2, dim_head=64, heads=2, num_queries=16, embedding_dim=96,
+        output_dim=unet.config.cross_attention_dim,
+        ff_mult=2
+    )
+    image_proj = image_proj.to(dtype=torch.float16, device=args.device)
+    attn_procs = {}
+    st = unet.state_dict()
+    for name in unet.attn_processors.keys():
+        cross_attention_dim = None if name.endswith("attn1.processor") else unet.config.cross_attention_dim
+        if name.startswith("mid_block"):
+            hidden_size = unet.config.block_out_channels[-1]
+        elif name.startswith("up_blocks"):
+            block_id = int(name[len("up_blocks."):].split(".")[0])
+            hidden_size = list(reversed(unet.config.block_out_channels))[block_id]
+        elif name.startswith("down_blocks"):
+            block_id = int(name[len("down_blocks."):].split(".")[0])
+            hidden_size = unet.config.block_out_channels[block_id]
+        if cross_attention_dim is None:
+            attn_procs[name] = RefSAttnProcessor2_0(name, hidden_size)
+        else:
+            attn_procs[name] = CAttnProcessor2_0(name, hidden_size=hidden_size, cross_attention_dim=cross_attention_dim)
+    unet.set_attn_processor(attn_procs)
+    adapter_modules = torch.nn.ModuleList(unet.attn_processors.values())
+    adapter_modules = adapter_modules.to(dtype=torch.float16, device=args.device)
+    del st
+    ref_unet = UNet2DConditionModel.from_pretrained(str(tmp_path / "rv"), subfolder="unet").to(
+        dtype=torch.float16,
+        device=args.device)
+    ref_unet.set_attn_processor(
+        {name: CacheAttnProcessor2_0() for name in ref_unet.attn_processors.keys()})  # set cache
+    model_sd = torch.load(args.model_ckpt, map_location="cpu")["module"]
+    ref_unet_dict = {}
+    unet_dict = {}
+    image_proj_dict = {}
+    adapter_modules_dict = {}
+    for k in model_sd.keys():
+        if k.startswith("ref_unet"):
+            ref_unet_dict[k.replace("ref_unet.", "")] = model_sd[k]
+        elif k.startswith("unet"):
+            unet_dict[k.replace("unet.", "")] = model_sd[k]
+        elif k.startswith("proj"):
+            image_proj_dict[k.replace("proj.", "")] = model_sd[k]
+        elif k.startswith("adapter_modules"):
+            adapter_modules_dict[k.replace("adapter_modules.", "")] = model_sd[k]
+        else:
+            raise AssertionError(k)
+    ref_unet.load_state_dict(ref_unet_dict)
+    image_proj.load_state_dict(image_proj_dict)
+    adapter_modules.load_state_dict(adapter_modules_dict)
+    noise_scheduler = DDIMScheduler(
+        num_train_timesteps=1000,
+        beta_start=0.00085,
+        beta_end=0.012,
+        beta_schedule="scaled_linear",
+        clip_sample=False,
+        set_alpha_to_one=False,
+        steps_offset=1,
+    )
+    pipe = IMAGDressing_v1(unet=unet, reference_unet=ref_unet, vae=vae, tokenizer=None,
+                           text_encoder=None, image_encoder=None,
+                           ImgProj=image_proj,
+                           scheduler=noise_scheduler,
+                           safety_checker=StableDiffusionSafetyChecker,
+                           feature_extractor=CLIPImageProcessor)
+    # ================= end of prepare() =================
+    assert all(isinstance(p, CacheAttnProcessor2_0) for p in ref_unet.attn_processors.values())     # kept across load_state_dict
+    twin = IMAGDressing_v1(unet=pair["e_unet"], reference_unet=pair["e_ref"], vae=None, tokenizer=None, text_encoder=None,
+                           image_encoder=None, ImgProj=proj0.to(device="cuda", dtype=torch.float16),
+                           scheduler=DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                                   clip_sample=False, set_alpha_to_one=False, steps_offset=1),
+                           safety_checker=None, feature_extractor=None)
+    kw = dict(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=128, height=128, num_inference_steps=4,
+              guidance_scale=7.5, num_images_per_prompt=1, image_scale=1.0, generator=generator,
+              prompt_embeds=g(10, 1, 77, 64, scale=0.5).cuda(), negative_prompt_embeds=g(11, 1, 77, 64, scale=0.5).cuda(),
+              ref_clip_hidden_states=g(12, 1, 20, 96, scale=0.5).cuda().half(), ref_image_latents=g(13, 1, 4, 16, 16).cuda(),
+              latents=g(14, 1, 4, 16, 16).cuda(), output_type="latent")
+    a = pipe(**kw).images
+    b = twin(**kw).images
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    pipe.set_scale(0.25)
+    assert all(p.scale == 0.25 for p in unet.attn_processors.values() if isinstance(p, RefSAttnProcessor2_0))
+    # the VAE handle built by from_pretrained decodes (output_type="pt") through the script's call sequence (:544-546)
+    img = pipe(**dict(kw, output_type="pt")).images
+    assert img.shape == (1, 3, 128, 128) and torch.isfinite(img).all() and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+
+
 @torch.no_grad()
 def test_pipeline_unipc_sampler_small():
     """UniPC through the pipeline == the same coefficient lists applied by hand in fp64 to the same UNet

@@ -6,7 +6,7 @@ import torch
 
 from oracle import processors as P
 from oracle import resampler as R
-from tests.cases import cross_inputs, hybrid_inputs, proj_plus_inputs, resampler_inputs
+from tests.cases import cache_inputs, cross_inputs, hybrid_inputs, proj_plus_inputs, resampler_inputs
 
 ATOL = 2e-5
 
@@ -56,6 +56,40 @@ def test_cache_restatement(golden_processors):
     p = P.CacheAttn()
     out = p(a, c["x"])
     assert p.cache["hidden_states"] is c["x"]
+    _close(out, c["out"])
+
+
+@pytest.mark.parametrize("name", ["hybrid_d40_n4096", "hybrid_d40_spike"])
+def test_hybrid_restatement_full_size(golden_full, name):
+    """The restatement against the reference source at the benchmarked kernel shape (N = M = 4096, C = 320) and on the
+    spiked ragged case; the fixtures keep a seeded subset of the output rows."""
+    c = golden_full[name]
+    i = hybrid_inputs(c)
+    args = (i["x"], i["wq"], i["wk"], i["wv"], i["wo"], i["bo"], c["heads"])
+    cond = P.hybrid_self_attention(*args, ref=i["ref"], wk_ref=i["wk_ref"], wv_ref=i["wv_ref"], scale=c["scale"])
+    unc = P.hybrid_self_attention(*args)
+    tol = ATOL * max(1.0, c["out_cond"].abs().max().item())       # spiked rows reach |out| ~ 30
+    _close(cond[:, c["rows"]], c["out_cond"], tol)
+    _close(unc[:, c["rows"]], c["out_uncond"], tol)
+    assert (c["out_cond"] - c["out_uncond"]).abs().max() > 1e-2
+    if c["spike"]:      # the spiked query row is (numerically) one-hot on the spiked key: the case is not a flat softmax
+        assert c["out_uncond"].abs().max() > 5.0
+
+
+@pytest.mark.parametrize("name", ["cache_d40", "cache_d80_cross"])
+def test_cache_restatement_real_dims(golden_full, name):
+    c = golden_full[name]
+    i = cache_inputs(c)
+
+    class A:
+        heads = c["heads"]
+    a = A()
+    lin = lambda w, b=None: type("L", (), {"weight": w, "bias": b})()
+    a.to_q, a.to_k, a.to_v = lin(i["wq"]), lin(i["wk"]), lin(i["wv"])
+    a.to_out = [lin(i["wo"], i["bo"])]
+    p = P.CacheAttn()
+    out = p(a, i["x"], encoder_hidden_states=i["ehs"])
+    assert p.cache["hidden_states"] is i["x"]
     _close(out, c["out"])
 
 

@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.cases import cross_inputs, hybrid_inputs, proj_plus_inputs, resampler_inputs  # noqa: E402
+from tests.cases import cache_inputs, cross_inputs, hybrid_inputs, proj_plus_inputs, resampler_inputs  # noqa: E402
 
 DT = pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 ATOL = {torch.float16: 1e-2, torch.bfloat16: 4e-2}
@@ -94,6 +94,152 @@ def test_cross_processor_vs_reference_golden(golden_processors, name, dt):
     check(out, c["out"], dt, name)
     out2 = attn(i["x"].cuda().to(dt), encoder_hidden_states=ehs)          # second call hits the cached K/V
     assert torch.equal(out, out2)
+
+
+# ---- the reference source at the BENCHMARKED kernel shape, a spiked ragged case, CacheAttn at real head dims ----------
+FULL_ATOL = {torch.float16: 1e-2, torch.bfloat16: 4e-2}
+FULL_RTOL = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}     # spiked rows reach |out| ~ 30: 2 / 4 ulp of the element type
+
+
+def check_rows(got, ref, dt, what):
+    e = (got.float().cpu() - ref).abs()
+    bad = e > FULL_ATOL[dt] + FULL_RTOL[dt] * ref.abs()
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} elements off, max abs err {e.max().item():.4g}, ref max {ref.abs().max().item():.3g}"
+
+
+@DT
+@pytest.mark.parametrize("name", ["hybrid_d40_n4096", "hybrid_d40_spike"])
+@torch.no_grad()
+def test_hybrid_processor_benchmarked_shape_vs_reference_golden(golden_full, name, dt):
+    """N = M = 4096, C = 320 is the level-0 shape bench.py's roofline times: N >= 512 dispatches the two-query-blocks-per-wave
+    instantiation of the fused kernel, with the garment phase, against outputs of the REFERENCE source
+    (adapter/attention_processor.py:531-627).  The spiked case (N = 840, M = 700, three tokens scaled x12 late in the
+    sequences) forces the kernel's deferred-max redo / rescale path on that instantiation and ends in a ragged tile."""
+    from imagdressing_amd.adapter import attention_processor as A
+    c = golden_full[name]
+    i = hybrid_inputs(c)
+    attn = make_attn(i, c["heads"], dt)
+    pname = "blk.attn1.processor"
+    proc = A.RefSAttnProcessor2_0(pname, c["C"], scale=c["scale"])
+    proc.to_k_ref.weight.copy_(i["wk_ref"]); proc.to_v_ref.weight.copy_(i["wv_ref"])
+    attn.set_processor(proc)
+    x = i["x"].cuda().to(dt)
+    ref = i["ref"].cuda()
+    rows = c["rows"]
+    cond = attn(x, sa_hidden_states={pname: ref})
+    check_rows(cond[:, rows], c["out_cond"], dt, f"{name} cond")
+    unc = attn(x)
+    check_rows(unc[:, rows], c["out_uncond"], dt, f"{name} uncond")
+    # the CFG layout of the pipeline: [cond; uncond] rows in ONE launch, garment switched per row
+    both = attn(torch.cat([x, x]), sa_hidden_states={pname: ref}, sa_batch_mask=torch.tensor([1.0, 0.0], device="cuda"))
+    check_rows(both[0:1, rows], c["out_cond"], dt, f"{name} CFG row 0")
+    check_rows(both[1:2, rows], c["out_uncond"], dt, f"{name} CFG row 1")
+
+
+@DT
+@pytest.mark.parametrize("name", ["cache_d40", "cache_d80_cross"])
+@torch.no_grad()
+def test_cache_processor_vs_reference_golden(golden_full, name, dt):
+    """``CacheAttnProcessor2_0`` (attention_processor.py:24-100) at SD1.5 head dims: stores its input, then plain self-attention
+    or -- the garment UNet's attn2 -- cross-attention over the 16 resampler tokens."""
+    from imagdressing_amd.adapter import attention_processor as A
+    c = golden_full[name]
+    i = cache_inputs(c)
+    attn = make_attn(i, c["heads"], dt)
+    p = A.CacheAttnProcessor2_0(); attn.set_processor(p)
+    x = i["x"].cuda().to(dt)
+    ehs = None if i["ehs"] is None else i["ehs"].cuda()
+    out = attn(x, encoder_hidden_states=ehs)
+    assert p.cache["hidden_states"] is x
+    check(out, c["out"], dt, name)
+
+
+# ---- the section-8b boundary: processors driven by a module that has ONLY the diffusers Attention surface ------------
+class _DiffusersLikeAttention(torch.nn.Module):
+    """What a diffusers ``Attention`` exposes to a processor (attention_processor.py:545-625) and nothing else: no
+    ``.packed``, no engine types; ``forward`` follows diffusers' ``Attention.forward`` (``self.processor(self, ...)``)."""
+
+    def __init__(self, c, kdim, heads):
+        super().__init__()
+        self.heads = heads
+        self.to_q = torch.nn.Linear(c, c, bias=False)
+        self.to_k = torch.nn.Linear(kdim, c, bias=False)
+        self.to_v = torch.nn.Linear(kdim, c, bias=False)
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(c, c), torch.nn.Dropout(0.0)])
+        self.spatial_norm = self.group_norm = self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+        self.processor = None
+
+    def prepare_attention_mask(self, m, *a, **k):
+        return m
+
+    def set_processor(self, p):
+        self.processor = p
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **cross_attention_kwargs):
+        return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                              attention_mask=attention_mask, **cross_attention_kwargs)
+
+
+def diffusers_like(i, c, kdim, heads, dtype):
+    a = _DiffusersLikeAttention(c, kdim, heads)
+    a.to_q.weight.copy_(i["wq"]); a.to_k.weight.copy_(i["wk"]); a.to_v.weight.copy_(i["wv"])
+    a.to_out[0].weight.copy_(i["wo"]); a.to_out[0].bias.copy_(i["bo"])
+    return a.to(device="cuda", dtype=dtype)      # inference_IMAGdressing.py:50-52
+
+
+@pytest.mark.parametrize("mdt", [torch.float16, torch.bfloat16, torch.float32], ids=["f16", "bf16", "f32-module"])
+@torch.no_grad()
+def test_processors_on_plain_diffusers_attention_surface(golden_processors, mdt):
+    """``unet.set_attn_processor(attn_procs)`` on whatever UNet the script built (inference_IMAGdressing.py:85-87): the
+    processors must work from ``attn.heads / to_q / to_k / to_v / to_out`` alone.  A torch ``nn.Module`` with exactly that
+    surface (fp16 / bf16 weights as after ``.to(dtype=...)``, or fp32 weights -> computed in fp16) gives the reference
+    golden outputs, returns the caller's dtype, and picks up in-place weight edits."""
+    from imagdressing_amd.adapter import attention_processor as A
+    cdt = mdt if mdt != torch.float32 else torch.float16
+    # hybrid self-attention (RefS) ...
+    c = golden_processors["hybrid_d40"]
+    i = hybrid_inputs(c)
+    attn = diffusers_like(i, c["C"], c["C"], c["heads"], mdt)
+    pname = "blk.attn1.processor"
+    proc = A.RefSAttnProcessor2_0(pname, c["C"], scale=c["scale"]).to(device="cuda", dtype=mdt)     # :86-87
+    proc.to_k_ref.weight.copy_(i["wk_ref"]); proc.to_v_ref.weight.copy_(i["wv_ref"])
+    attn.set_processor(proc)
+    x = i["x"].cuda().to(mdt)
+    cond = attn(x, sa_hidden_states={pname: i["ref"].cuda().to(mdt)})
+    assert cond.dtype == mdt and cond.shape == x.shape
+    check(cond, c["out_cond"], cdt, "diffusers-like hybrid cond")
+    check(attn(x), c["out_uncond"], cdt, "diffusers-like hybrid uncond")
+    # reference garment layout [B, M, C] (its own view(batch_size, ...), :602-603): one garment per row
+    refB = i["ref"].cuda().to(mdt).expand(x.shape[0], -1, -1).contiguous()
+    check(attn(x, sa_hidden_states={pname: refB}), c["out_cond"], cdt, "garment per row")
+    with pytest.raises(ValueError):
+        attn(torch.cat([x, x[:1]]), sa_hidden_states={pname: refB})          # 2 garments cannot serve 3 rows
+    # in-place weight edit is seen (cached concatenations are keyed by parameter version)
+    attn.to_out[0].bias.add_(1.0)
+    check(attn(x), c["out_uncond"] + 1.0, cdt, "bias edit")
+    # ... text cross-attention (CAttn), [B, C, H, W] input form (:548-552) ...
+    c = golden_processors["cross_d40"]
+    i = cross_inputs(c)
+    attn = diffusers_like(i, c["C"], c["KD"], c["heads"], mdt)
+    attn.set_processor(A.CAttnProcessor2_0("blk.attn2.processor", c["C"], c["KD"]))
+    x = i["x"].cuda().to(mdt)
+    out = attn(x, encoder_hidden_states=i["ehs"].cuda().to(mdt), sa_hidden_states={"unused": None})
+    check(out, c["out"], cdt, "diffusers-like cross")
+    # ... and IP-Adapter without LoRA (IPAttnProcessor2_0, :873-1003): its own test, with lora_scale = 0 in the oracle
+    from oracle import processors as OP
+    c = golden_processors["cross_d160_ip"]
+    i = cross_inputs(c)
+    attn = diffusers_like(i, c["C"], c["KD"], c["heads"], mdt)
+    ipp = A.IPAttnProcessor2_0(c["C"], c["KD"], scale=0.7, num_tokens=c["ip_tokens"]).to(device="cuda", dtype=mdt)
+    ipp.to_k_ip.weight.copy_(i["wk_ip"]); ipp.to_v_ip.weight.copy_(i["wv_ip"])
+    attn.set_processor(ipp)
+    want = OP.ip_cross_attention(i["x"], i["ehs"], i["wq"], i["wk"], i["wv"], i["wo"], i["bo"], c["heads"], i["wk_ip"], i["wv_ip"],
+                                 scale=0.7, num_tokens=c["ip_tokens"])
+    check(attn(i["x"].cuda().to(mdt), encoder_hidden_states=i["ehs"].cuda().to(mdt)), want, cdt, "IPAttnProcessor2_0")
+    with pytest.raises(NotImplementedError):
+        attn(i["x"].cuda().to(mdt), encoder_hidden_states=i["ehs"].cuda().to(mdt), attention_mask=torch.zeros(1, 1, 81, device="cuda"))
 
 
 @DT
