@@ -204,7 +204,11 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
         const int kfrag = swap23(col) * C::KSTR + hi * 16;   // permuted key row of this lane
         const int vfrag = col * VSTR + hi * 16;
         for (int t = 0; t < ntiles; ++t) {
-            if (t + 1 < ntiles) load_tile(t + 1);
+            // SCHED & 2: issue the next tile's loads unconditionally (past the last tile the K offsets are out of range and
+            // read as 0, the V^T ones alias rows that are never stored): a conditional load makes the staging registers
+            // loop-carried, and hipcc then copies them right after the loads, i.e. waits for the data at the TOP of the tile
+            // instead of at the LDS writes at its end
+            if ((SCHED & 2) || t + 1 < ntiles) load_tile(t + 1);
             const char* Vs = smem + (t & 1) * C::BUF;
             const char* Ks = Vs + C::VBYTES;
             const bool ragged = (t + 1) * KT > L;
@@ -463,6 +467,7 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     switch (p.D) {
         case 40:
             if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 1>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 1>(p, s);
+            if (g_attn_qw40 == 5 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 3>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 3>(p, s);
             if (g_attn_qw40 == 3) return h ? launch_attn<true, 40, 1, 3, 2, false>(p, s) : launch_attn<false, 40, 1, 3, 2, false>(p, s);
             if (g_attn_qw40 == 4) return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
             if (g_attn_qw40 == 1 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 0>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 0>(p, s);

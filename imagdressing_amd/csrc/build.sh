@@ -6,18 +6,23 @@ cd "$(dirname "$0")"
 OUT=../libimagdressing_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function ${IMD_EXTRA_FLAGS:-}"
 objs=()
+pids=()
 for f in conv_gemm.hip conv_patch.hip attention.hip norm.hip elementwise.hip; do
   o="build/${f%.hip}.o"; mkdir -p build
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ imd_kernels.h -nt "$o" ] || [ gemm_common.h -nt "$o" ] || [ ../../include/imagdressing_hip.h -nt "$o" ]; then
+    rm -f "$o"                      # a failed compile must not leave a stale object for the link step
     hipcc $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
   fi
   objs+=("$o")
 done
 o=build/capi.o
 if [ ! -f "$o" ] || [ capi.cpp -nt "$o" ] || [ imd_kernels.h -nt "$o" ] || [ gemm_common.h -nt "$o" ] || [ ../../include/imagdressing_hip.h -nt "$o" ]; then
+  rm -f "$o"
   hipcc $FLAGS -x hip -c capi.cpp -o "$o" &
+  pids+=($!)
 fi
 objs+=("$o")
-wait
+for pid in ${pids[@]+"${pids[@]}"}; do wait "$pid" || { echo "build.sh: a compile job failed" >&2; exit 1; }; done
 hipcc --offload-arch=gfx950 -shared -fPIC "${objs[@]}" -o "$OUT"
 echo "built $(realpath $OUT)"

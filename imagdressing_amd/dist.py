@@ -63,13 +63,22 @@ def feature_layout(unet_like, ref_hw: Tuple[int, int]) -> List[Tuple[str, tuple]
     h, w = ref_hw
     layout = []
     level_of = {}
+    # a stride-2 3x3 conv with padding 1 maps n -> ceil(n / 2) (odd latent sizes round UP, level by level)
+    hs, ws = [int(h)], [int(w)]
+    for _ in range(len(boc) - 1):
+        hs.append((hs[-1] + 1) // 2)
+        ws.append((ws[-1] + 1) // 2)
+    if hs[-1] * 2 ** (len(boc) - 1) != hs[0] or ws[-1] * 2 ** (len(boc) - 1) != ws[0]:
+        # the up path doubles sizes back: only latents divisible by 2^(levels-1) make the skip shapes line up (as in
+        # diffusers); say so on EVERY rank before anybody enters the collective
+        raise ValueError(f"garment latent {h}x{w} is not divisible by {2 ** (len(boc) - 1)}: the UNet's skip connections would not line up")
     for i, ch in enumerate(boc):
-        level_of[f"down_blocks.{i}"] = (ch, (h >> i) * (w >> i))
+        level_of[f"down_blocks.{i}"] = (ch, hs[i] * ws[i])
     rev = list(reversed(boc))
     for i, ch in enumerate(rev):
         lv = len(boc) - 1 - i
-        level_of[f"up_blocks.{i}"] = (ch, (h >> lv) * (w >> lv))
-    level_of["mid_block"] = (boc[-1], (h >> (len(boc) - 1)) * (w >> (len(boc) - 1)))
+        level_of[f"up_blocks.{i}"] = (ch, hs[lv] * ws[lv])
+    level_of["mid_block"] = (boc[-1], hs[-1] * ws[-1])
     for name in unet_like.attn_processors.keys():
         key = name.split(".attentions")[0]
         ch, tokens = level_of[key]
@@ -94,8 +103,11 @@ def garment_features_broadcast(pipe, ref_latents: torch.Tensor, cloth_tokens: to
     if rank() == 0:
         feats = pipe.garment_features(ref_latents, cloth_tokens)
         flat, lay0 = pack_features({n: feats[n].to(runet.dtype) for n in names}, names)
-        assert lay0 == layout, "garment feature layout mismatch"
+        if lay0 != layout:       # never leave the other ranks blocked in the broadcast: send what they expect, then raise
+            flat = torch.full((total,), float("nan"), dtype=runet.dtype, device=pipe.device)
     else:
         flat = torch.empty(total, dtype=runet.dtype, device=pipe.device)
     broadcast_packed(flat, 0)
+    if rank() == 0 and lay0 != layout:
+        raise RuntimeError(f"garment feature layout mismatch: derived {layout[:2]}..., garment UNet produced {lay0[:2]}...")
     return unpack_features(flat, layout)

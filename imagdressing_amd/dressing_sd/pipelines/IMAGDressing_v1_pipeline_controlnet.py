@@ -21,12 +21,13 @@ class IMAGDressing_v1(PipelineBase):
     def set_scale(self, scale):                                              # :352-355
         set_scale_by_type(self.unet, RefSAttnProcessor2_0, scale=scale)
 
-    def _control(self, pose_image, prompt_embeds, negative_prompt_embeds, num_inference_steps, scale, start, end, device):
+    def _control(self, pose_image, prompt_embeds, negative_prompt_embeds, num_inference_steps, scale, start, end, device, size=None):
         """ControlNet inputs: the pose image (shared by the CFG halves, :497-498) and the TEXT-ONLY embeddings
         (``prompt_embeds_control``, ..._ipa_controlnet.py:550)."""
         if pose_image is None:
             return None
-        return dict(image=to_image_tensor(pose_image, device, normalize=False), prompt_embeds=prompt_embeds,
+        return dict(image=to_image_tensor(pose_image, device, normalize=False, size=size, multiple=self.vae_scale_factor),
+                    prompt_embeds=prompt_embeds,
                     negative_prompt_embeds=negative_prompt_embeds, scale=float(first(scale)),
                     keep=controlnet_keep(num_inference_steps, float(first(start)), float(first(end))))
 
@@ -54,7 +55,8 @@ class IMAGDressing_v1(PipelineBase):
         else:
             cloth_tokens = self._cloth_tokens(ref_clip_image, ref_clip_hidden_states, device)
         control = self._control(pose_image, prompt_embeds, negative_prompt_embeds, num_inference_steps,
-                                controlnet_conditioning_scale, control_guidance_start, control_guidance_end, device)
+                                controlnet_conditioning_scale, control_guidance_start, control_guidance_end, device,
+                                size=(height, width))
         if control is not None:
             height, width = control["image"].shape[-2:]                     # :501
         lat = self._shard(self.prepare_latents(num_images_per_prompt, 4, width, height, torch.float32, device, generator, latents),

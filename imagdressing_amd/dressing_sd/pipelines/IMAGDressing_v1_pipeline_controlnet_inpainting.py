@@ -22,10 +22,10 @@ class IMAGDressing_v1(PipelineBase):
     def set_scale(self, scale):
         set_scale_by_type(self.unet, RefSAttnProcessor2_0, scale=scale)
 
-    def _image_latents(self, image, device, generator):
+    def _image_latents(self, image, device, generator, size=None):
         """VAE-encode the person image (inherited ``prepare_latents(..., return_image_latents=True)``, :330-346)."""
         p = next(self.vae.parameters())
-        x = to_image_tensor(image, p.device, normalize=True).to(p.dtype)
+        x = to_image_tensor(image, p.device, normalize=True, size=size, multiple=self.vae_scale_factor).to(p.dtype)
         return self.vae.encode(x).latent_dist.sample(generator) * self.vae.config.scaling_factor
 
     @torch.no_grad()
@@ -57,7 +57,8 @@ class IMAGDressing_v1(PipelineBase):
             cloth_tokens, _ = self.encode_prompt(null_prompt, device, 1, False)
         else:
             cloth_tokens = self._cloth_tokens(ref_clip_image, ref_clip_hidden_states, device)
-        control = dict(image=to_image_tensor(control_image, device, normalize=False), prompt_embeds=prompt_embeds,
+        control = dict(image=to_image_tensor(control_image, device, normalize=False, size=(height, width), multiple=self.vae_scale_factor),
+                       prompt_embeds=prompt_embeds,
                        negative_prompt_embeds=negative_prompt_embeds, scale=float(first(controlnet_conditioning_scale)),
                        keep=controlnet_keep(num_inference_steps, float(first(control_guidance_start)), float(first(control_guidance_end))))
         B = num_images_per_prompt
@@ -68,7 +69,7 @@ class IMAGDressing_v1(PipelineBase):
         lat = noise.to(device=device, dtype=torch.float32) if latents is None else latents.to(device=device, dtype=torch.float32)
         lat = lat * self.scheduler.init_noise_sigma
         if image_latents is None:
-            image_latents = self._image_latents(image, device, generator)
+            image_latents = self._image_latents(image, device, generator, size=(height, width))
         if mask_latents is None:                                              # prepare_mask_latents: nearest resize to h x w
             m = to_image_tensor(mask_image, device, normalize=False)[:, :1]
             m = (m >= 0.5).float()

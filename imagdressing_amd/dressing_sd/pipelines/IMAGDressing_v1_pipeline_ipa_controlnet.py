@@ -98,7 +98,8 @@ class IMAGDressing_v1(PipelineBase):
             negative_prompt_embeds=negative_prompt_embeds, clip_skip=clip_skip)
         control = None
         if pose_image is not None:                                            # ControlNet sees the 77 text tokens only (:550)
-            control = dict(image=to_image_tensor(pose_image, device, normalize=False), prompt_embeds=prompt_embeds,
+            control = dict(image=to_image_tensor(pose_image, device, normalize=False, size=(height, width), multiple=self.vae_scale_factor),
+                           prompt_embeds=prompt_embeds,
                            negative_prompt_embeds=negative_prompt_embeds, scale=float(first(controlnet_conditioning_scale)),
                            keep=controlnet_keep(num_inference_steps, float(first(control_guidance_start)),
                                                 float(first(control_guidance_end))))

@@ -259,9 +259,18 @@ def first(x):
     return x[0] if isinstance(x, (list, tuple)) else x
 
 
-def to_image_tensor(image, device, normalize: bool) -> torch.Tensor:
-    """PIL / ndarray / tensor -> [B, 3, H, W] float in [0, 1] (or [-1, 1] when ``normalize``)."""
+def to_image_tensor(image, device, normalize: bool, size=None, multiple: int = 8) -> torch.Tensor:
+    """PIL / ndarray / tensor -> [B, 3, H, W] float in [0, 1] (or [-1, 1] when ``normalize``).
+
+    ``size`` = (height, width) requested by the caller: like diffusers' ``prepare_image`` /
+    ``VaeImageProcessor.preprocess`` (call sites ..._controlnet.py:480-501, ..._inpainting.py:352-369) the image is resized
+    to it, rounded DOWN to a multiple of ``multiple`` (the VAE scale factor) -- PIL inputs with PIL's Lanczos filter (the
+    processor's default ``resample``), tensors / arrays with ``F.interpolate``'s default (nearest), as the library does.
+    The pipelines then read the output size back from this tensor (:501), so it always divides by 8."""
     import numpy as np
+    hw = None
+    if size is not None:
+        hw = (int(size[0]) // multiple * multiple, int(size[1]) // multiple * multiple)
     if isinstance(image, torch.Tensor):
         t = image.float()
         if t.dim() == 3:
@@ -269,10 +278,19 @@ def to_image_tensor(image, device, normalize: bool) -> torch.Tensor:
     else:
         if not isinstance(image, (list, tuple)):
             image = [image]
-        arrs = [np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.float32) / 255.0 for im in image]
-        t = torch.from_numpy(np.stack(arrs)).permute(0, 3, 1, 2)
+        ims = []
+        for im in image:
+            if hasattr(im, "convert"):
+                im = im.convert("RGB")
+                if hw is not None and (im.height, im.width) != hw:
+                    from PIL import Image
+                    im = im.resize((hw[1], hw[0]), resample=Image.LANCZOS)
+            ims.append(np.asarray(im, dtype=np.float32) / 255.0)
+        t = torch.from_numpy(np.stack(ims)).permute(0, 3, 1, 2)
         if normalize:
             t = t * 2.0 - 1.0
+    if hw is not None and tuple(t.shape[-2:]) != hw:
+        t = torch.nn.functional.interpolate(t, size=hw)
     return t.to(device)
 
 

@@ -183,6 +183,10 @@ def conv_gemm(
                 cfg, split_k = ent["cfg"], ent["split"]
             else:
                 cfg, split_k = ent["cfg_nosplit"], 1
+            # the table is keyed by (M, N, K, taps, stride, ups) only: another geometry with the same key (W % 16 != 0,
+            # pad_br_only, strided pixels ...) may not qualify for the halo-patch kernel -> back to the library heuristic
+            if cfg == 5 and not lib.imd_conv_patch_supported(C.byref(p)):
+                cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
     if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and not ups and Wout >= PATCH_MIN_W and N >= 64 \

@@ -34,7 +34,8 @@ def check(got, ref, dt, what):
 
 
 @DT
-@pytest.mark.parametrize("name", ["hybrid_small", "hybrid_small_lora", "hybrid_d40", "hybrid_d80", "hybrid_d160", "hybrid_d40_lora"])
+# (the head-dim-8 "small" fixtures pin the CPU restatement only, tests/test_oracle_golden.py: no SD1.5 layer has d = 8)
+@pytest.mark.parametrize("name", ["hybrid_d40", "hybrid_d80", "hybrid_d160", "hybrid_d40_lora"])
 @torch.no_grad()
 def test_hybrid_processor_vs_reference_golden(golden_processors, name, dt):
     if not torch.cuda.is_available():
@@ -70,7 +71,7 @@ def test_hybrid_processor_vs_reference_golden(golden_processors, name, dt):
 
 
 @DT
-@pytest.mark.parametrize("name", ["cross_small", "cross_small_ip", "cross_d40", "cross_d160_ip"])
+@pytest.mark.parametrize("name", ["cross_d40", "cross_d160_ip"])
 @torch.no_grad()
 def test_cross_processor_vs_reference_golden(golden_processors, name, dt):
     if not torch.cuda.is_available():
@@ -240,23 +241,6 @@ def test_processors_on_plain_diffusers_attention_surface(golden_processors, mdt)
     check(attn(i["x"].cuda().to(mdt), encoder_hidden_states=i["ehs"].cuda().to(mdt)), want, cdt, "IPAttnProcessor2_0")
     with pytest.raises(NotImplementedError):
         attn(i["x"].cuda().to(mdt), encoder_hidden_states=i["ehs"].cuda().to(mdt), attention_mask=torch.zeros(1, 1, 81, device="cuda"))
-
-
-@DT
-@torch.no_grad()
-def test_cache_processor_stores_input(golden_processors, dt):
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    from imagdressing_amd.adapter import attention_processor as A
-    c = golden_processors["cache_small"]
-    if c["C"] // c["heads"] not in (40, 64, 80, 160):
-        pytest.skip("fixture head dim 8 is not an SD1.5 head dim")
-    attn = make_attn(c, c["heads"], dt)
-    p = A.CacheAttnProcessor2_0(); attn.set_processor(p)
-    x = c["x"].cuda().to(dt)
-    out = attn(x)
-    assert p.cache["hidden_states"] is x
-    check(out, c["out"], dt, "cache")
 
 
 @DT
