@@ -42,7 +42,7 @@ class AttnParams(C.Structure):
         ("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("D", C.c_int),
         ("L1", C.c_int), ("L1P", C.c_int), ("kv1_bdiv", C.c_int),
         ("L2", C.c_int), ("L2P", C.c_int), ("kv2_bdiv", C.c_int),
-        ("out_ld", C.c_int), ("dtype", C.c_int), ("flags", C.c_int), ("causal", C.c_int),
+        ("out_ld", C.c_int), ("dtype", C.c_int), ("flags", C.c_int), ("causal", C.c_int), ("k_pad_one", C.c_int),
     ]
 
 
@@ -118,8 +118,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if lib.imd_abi_version() != 1:
-            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 1")
+        if lib.imd_abi_version() != 2:
+            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 2")
         _lib = lib
     return _lib
 

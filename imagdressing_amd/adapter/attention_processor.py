@@ -167,7 +167,7 @@ def _project_kv(tokens: torch.Tensor, wkv: torch.Tensor, heads: int):
     D = Cc // heads
     dpk, dpv = ops.attn_padded_dims(D)
     LP = ops.pad64(Lk)
-    k = torch.zeros(Bk, heads, Lk, dpk, dtype=wkv.dtype, device=tokens.device)
+    k = ops.k_buffer((Bk, heads, Lk, dpk), D, wkv.dtype, tokens.device)
     vt = torch.zeros(Bk, heads, dpv, LP, dtype=wkv.dtype, device=tokens.device)
     ops.conv_gemm(tokens.view(Bk * Lk, Kd), wkv, M=Bk * Lk, N=2 * Cc, Cin=Kd, Hin=Lk, Win=1, Hout=Lk, Wout=1,
                   heads=dict(C=Cc, H=heads, D=D, dests=[(k, 0, dpk, Lk, 1.0), (vt, 1, dpv, LP, 1.0)]))
@@ -187,7 +187,7 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
     x2 = x.view(B * N, Cc)
     if self_attn:
         LP = ops.pad64(N)
-        k = ops.workspace("attn_k", (B, heads, N, dpk), dt, dev)
+        k = ops.k_buffer((B, heads, N, dpk), D, dt, dev, tag="attn_k")
         vt = ops.workspace("attn_vt", (B, heads, dpv, LP), dt, dev)
         ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=3 * Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1,
                       heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale), (k, 0, dpk, N, 1.0), (vt, 1, dpv, LP, 1.0)]))
@@ -199,7 +199,8 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
     kw = {}
     if kv2 is not None and scale2 is not None:
         kw = dict(k2=kv2[0], v2t=kv2[1], L2=kv2[2], L2P=kv2[3], kv2_bdiv=kv2_bdiv, scale2=scale2)
-    ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, **kw)
+    # every K operand on this path comes from ops.k_buffer (pad column = 1): the d = 40 kernel may stage by LDS-DMA
+    ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True, **kw)
     res2 = None if residual is None else residual.view(B * N, Cc)
     return ops.linear(o.view(B * N, Cc), wo, bo, res=res2).view(B, N, Cc)
 

@@ -443,10 +443,15 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 // head-dim-40 kernel variant (tuning knob 0, imd_set_tuning(0, v)); all variants give the same result up to fp32 order:
-//   2 (default): 2 query blocks per wave, 32-key softmax blocks, speculative exp (measured +8 % over 3)
+//   9 (default): attention_d40.hip, software-pipelined steps with the MFMA / VALU interleave written out (N >= 512; shorter
+//      sequences and the causal mask fall through to variant 4 below), K / V^T staged by LDS-DMA when the caller guarantees
+//      K's pad column (imd_attn_params.k_pad_one), through registers otherwise;  7: always through registers;
+//      6: as 7 without the pinned interleave;  8: as 7 with the deferred-maximum bound 2^12;  10..15: timing ablations
+//   5: as 2 with the next tile's loads issued unconditionally (+7 % over 2)
+//   2: 2 query blocks per wave, 32-key softmax blocks, speculative exp (round-1 default)
 //   4: 1 query block per wave, 32-key blocks, speculative exp      3: 1 query block, 64-key blocks, exact max every block
 //   1: as 3 with speculative exp
-int g_attn_qw40 = 2;
+int g_attn_qw40 = 9;
 
 int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }
@@ -466,6 +471,7 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (p.D) {
         case 40:
+            if (g_attn_qw40 >= 6 && p.N >= 512 && !p.causal) return imd_launch_attention_d40(p, g_attn_qw40, s);
             if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 1>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 1>(p, s);
             if (g_attn_qw40 == 5 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 3>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 3>(p, s);
             if (g_attn_qw40 == 3) return h ? launch_attn<true, 40, 1, 3, 2, false>(p, s) : launch_attn<false, 40, 1, 3, 2, false>(p, s);

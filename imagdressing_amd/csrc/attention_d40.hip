@@ -1,0 +1,525 @@
+// Fused dual-softmax ("hybrid") attention for head dim 40 -- the UNet level-0 kernel (N = M = 4096 at 512x512: 88 % of the
+// hybrid-attention FLOPs of a denoising step, the kernel bench.py's roofline times).
+//
+//   O[b, q, h*40:(h+1)*40] = softmax(Q K1^T) V1  +  s2[b] * softmax(Q K2^T) V2
+//
+// = RefSAttnProcessor2_0.__call__ between the projections (/root/reference/adapter/attention_processor.py:589-612): frozen
+// self attention over the image tokens plus an independently normalised cross attention over the garment tokens, the two
+// half-precision results added (:612).  Same operand layouts, same C ABI entry (imd_attention) and the same arithmetic
+// ideas as the generic kernel in attention.hip (swapped S^T = K Q^T so that exp2'd, packed scores ARE the B operand of
+// O^T += V^T P^T; deferred row maximum folded into the QK^T MFMA through the pad column; softmax denominator produced by
+// the P.V MFMA through an all-ones V^T row); what differs is the SCHEDULE:
+//
+//   * software pipeline over 32-key steps, written out in the source: in step j a wave issues the QK^T MFMAs of block
+//     j+1, the P.V MFMAs of block j-1 and the exp2 / pack VALU work of block j -- three independent instruction streams in
+//     ONE basic block (14 MFMAs against ~60 VALU), which hipcc interleaves (sched_group_barrier pattern below) so that the
+//     matrix pipe runs underneath the transcendental work of the same wave instead of waiting for the other wave;
+//   * the only branch of a step is the (rare) "a score ran past the deferred maximum" test, taken once per step for both
+//     query blocks; the exact path behind it recomputes the block's scores from K in L2 (three 16-byte loads per lane),
+//     so the hot path keeps no copy of them.  First / ragged / past-the-end blocks use the same path (forced);
+//   * K and V^T are staged skewed by one block (unit u = K rows [64u+32, 64u+96) + V^T columns [64u-32, 64u+32)), so a
+//     unit serves exactly the two steps of one loop iteration and the double buffer still needs ONE barrier per 64 keys;
+//   * the next unit's global loads are issued unconditionally at the top of an iteration and consumed by the LDS writes
+//     at its end (a conditional prefetch makes the staging registers loop-carried and hipcc then waits for them at once);
+//   * the phase-0 (self) result of a two-phase row is parked in LDS (16-bit, the rounding the reference's first SDPA
+//     output has), not in the output buffer: no HBM round trip, no store -> load dependency at the phase boundary.
+#include <type_traits>
+
+#include "common.h"
+#include "imd_kernels.h"
+
+namespace {
+
+constexpr int D = 40, DPK = 48, DPV = 64, NKT = 3;
+constexpr int KT = 64;                      // keys per staged unit (two 32-key steps)
+constexpr int KSTR = DPK * 2 + 16;          // 112 B per K row in LDS  (7 x 16 B: conflict-free b128 fragment reads)
+constexpr int VSTR = KT * 2 + 16;           // 144 B per V^T row       (9 x 16 B)
+constexpr int VROWS = D + 1;                // 40 head-dim rows + the all-ones row that yields the softmax denominator
+constexpr int VBYTES = VROWS * VSTR;        // rows 41..63 of the second 32-row MFMA block are NOT stored: their fragment
+constexpr int BUF = VBYTES + KT * KSTR;     // reads run into the K rows behind (finite garbage into accumulator rows nobody reads)
+constexpr int PARK = 4 * 5 * 1024;          // phase-0 result: 4 waves x 20 packed dwords per lane
+static_assert((DPV - VROWS) * VSTR <= KT * KSTR, "phantom V^T rows must stay inside the K rows");
+// LDS-DMA staging (VAR & 128): `buffer_load ... lds` writes lane-linear (wave-uniform base + lane * 16 B), so rows cannot be
+// padded; bank conflicts are avoided by choosing WHICH 16-byte piece of global memory a lane fetches instead:
+//   K  : 96-byte rows back to back; the six pieces of rows 8..15 (mod 16) are stored rotated by three
+//   V^T: 128-byte rows back to back; piece c of row d is stored at position c ^ ((d >> 1) & 7)
+// (with either map the 16 rows a ds_read_b128 lane group touches fall on 16 distinct 16-byte bank slots)
+constexpr int KSTR_D = DPK * 2, VSTR_D = KT * 2, VBYTES_D = VROWS * VSTR_D, BUF_D = VBYTES_D + KT * KSTR_D;
+constexpr int LDS_BYTES_D = 2 * BUF_D + PARK;
+static_assert((DPV - VROWS) * VSTR_D <= KT * KSTR_D, "phantom V^T rows must stay inside the K rows");
+
+typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u;
+__device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
+    const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+constexpr uint32_t OOB = 0xffffffffu;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from `rsrc` at per-lane byte offset `voff` (out of range reads 0) to LDS bytes
+// [lds_addr, lds_addr + 1024).  Inline asm on purpose: through the builtin hipcc assumes the DMA may alias every later
+// ds_read of the kernel's one LDS array and drains it (s_waitcnt vmcnt(0)) in front of the first fragment read -- the
+// whole point is to keep it in flight for an iteration.  Completion is waited for by hand (dma_wait) before the barrier
+// that publishes the unit.  M0 (the DMA's LDS base) is saved and restored inside the statement; the leading s_nop covers a
+// descriptor / offset register written by a VALU just before (hipcc does not see hazards inside an asm string).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma16(const v4i_t& rsrc, uint32_t lds_addr, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ v4i_t raw_rsrc(const void* base, uint32_t bytes) {      // stride 0, raw addressing, wave-uniform by construction
+    const uint64_t a = (uint64_t)base;
+    v4i_t r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+// packed 3-input maximum: on non-negative 16-bit float patterns (fp16 OR bf16) it is the maximum of the patterns as
+// integers, with inf / NaN patterns propagating
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) {      // -> one v_pk_maximum3_f16
+    const h2_t x = __builtin_bit_cast(h2_t, a), y = __builtin_bit_cast(h2_t, b), z = __builtin_bit_cast(h2_t, c);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
+}
+
+// VAR bit 0: MFMA / VALU interleave written out and pinned   bit 1: plain (not XCD-aware) work order
+// ABLATION bits (timing experiments only, results are WRONG): 4: exp2 replaced by a move   8: no barrier in the loop
+//   16: no global loads / LDS stores in the loop   32: no P.V MFMAs   64: no QK^T MFMAs   256: one LDS fragment read per step
+//   512: 100 KB of LDS per workgroup (one workgroup = one wave per SIMD)
+template <bool F16, int THR, int VAR>
+__global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
+    using E = El<F16>;
+    constexpr bool DMA = (VAR & 128) != 0;
+    constexpr int BUFB = DMA ? BUF_D : BUF, VBY = DMA ? VBYTES_D : VBYTES;
+    constexpr float OFFS_THR = (float)THR;                 // deferred maximum: P <= 2^THR (base-2 units)
+    constexpr int QPAD_T = D / 16, QPAD_HI = (D % 16) / 8;  // Q fragment / half-wave holding pad slot 40 (element 0 of the fragment)
+    constexpr int L_DT = D / 32, L_REG = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_HI = ((D % 32) >> 2) & 1;   // accumulator row 40
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5;
+    const int col = lane & 31;
+    // XCD-aware work list (hardware block L runs on XCD L % 8): q-tile fastest, then batch, then head; every XCD gets a
+    // contiguous slice, i.e. all q-tiles that re-read one (batch, head)'s K / V^T share one L2, and every XCD sees the same mix
+    // of two-phase (garment) and one-phase rows
+    int wx, h, b;
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z, total = gx * gy * gz;
+        const unsigned Lb = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const unsigned xcd = Lb & 7u, slot = Lb >> 3;
+        const unsigned q8 = total >> 3, r8 = total & 7u;          // bijective also when total % 8 != 0
+        unsigned w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+        if ((VAR & 2) || (p.flags & 1)) w = Lb;
+        wx = (int)(w % gx);
+        b = (int)((w / gx) % gz);
+        h = (int)(w / (gx * gz));
+    }
+    const int q0 = (wx * 4 + wave) * 64;
+
+    // V^T row 40 (all ones) of both buffers: written once, never restaged
+    {
+        constexpr int PADV = (DMA ? VSTR_D : VSTR) / 16;
+        const uint32_t one2 = E::pack2(1.0f, 1.0f);
+        for (int v = tid; v < 2 * PADV; v += 256)
+            *reinterpret_cast<uint4*>(smem + (v / PADV) * BUFB + D * (DMA ? VSTR_D : VSTR) + (v % PADV) * 16) = make_uint4(one2, one2, one2, one2);
+    }
+
+    // Q fragments (B operand of S^T = K Q^T): lane = query column, 8 head-dim values per fragment
+    uint4 qf[2][NKT];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + qb * 32 + col;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q < p.N) v = *reinterpret_cast<const uint4*>(p.q + ((size_t)(b * p.H + h) * p.N + q) * DPK + t * 16 + hi * 8);
+            qf[qb][t] = v;
+        }
+    }
+
+    float w2 = 0.f;
+    if (p.k2 != nullptr && p.scale2 != nullptr) w2 = p.scale2[b];
+    const int nph = (w2 != 0.f) ? 2 : 1;
+
+    const int kfrag = swap23(col) * KSTR + hi * 16;      // permuted key row of this lane (see common.h::swap23)
+    const int vfrag = col * VSTR + hi * 16;
+    // DMA layout: fragment addresses of this lane (K chunk 2f + hi of row swap23(col); V^T piece 2g + hi of row col)
+    int kfd[3], vfd[4];
+    {
+        const int kr = swap23(col), rot = 3 * ((kr >> 3) & 1), sw = (col >> 1) & 7;
+#pragma unroll
+        for (int f = 0; f < 3; ++f) kfd[f] = kr * KSTR_D + ((2 * f + hi + rot) % 6) * 16;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vfd[g] = col * VSTR_D + (((2 * g + hi) ^ sw) * 16);
+    }
+    char* park = smem + 2 * BUFB + wave * 5120 + lane * 16;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int ph = 0; ph < nph; ++ph) {
+        f32x16 o[2][2];
+        float m_ref[2] = {0.f, 0.f};
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            if (hi == QPAD_HI) qf[qb][QPAD_T].x &= 0xffff0000u;       // Q pad slot = -m_ref = 0
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) o[qb][dt] = zero16;
+        }
+        const int L = ph ? p.L2 : p.L1;
+        const int LP = ph ? p.L2P : p.L1P;
+        const int kvb = ph ? (b / p.kv2_bdiv) : (b / p.kv1_bdiv);
+        const bf16_t* kbase = (ph ? p.k2 : p.k1) + (size_t)(kvb * p.H + h) * L * DPK;
+        const bf16_t* vbase = (ph ? p.v2t : p.v1t) + (size_t)(kvb * p.H + h) * DPV * LP;
+        const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(kbase), 0, (uint32_t)L * DPK * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(vbase), 0, (uint32_t)D * LP * 2, 0x00020000);
+        const int J = (L + 31) >> 5;                 // 32-key blocks
+        const int NU = (J >> 1) + 1;                 // units: steps 0 .. 2 NU - 1 cover P.V of block J - 1
+
+        // staging slots of this thread: K vectors v0 = tid, v1 = tid + 256 (< 384), V^T vectors likewise (< 320)
+        const int kr0 = tid / 6, kc0 = tid % 6, kr1 = (tid + 256) / 6, kc1 = (tid + 256) % 6;
+        const int vr0 = tid >> 3, vc0 = tid & 7, vr1 = (tid + 256) >> 3;
+        const bool k1ok = tid < 128, v1ok = tid < 64;
+        uint4 kreg0, kreg1, vreg0, vreg1;
+        auto load_unit = [&](int u) {        // K rows [64u+32, 64u+96), V^T columns [64u-32, 64u+32); out of range reads 0
+            const int krow = u * KT + 32, vcol = u * KT - 32;
+            kreg0 = buf_load16(rs_k, (krow + kr0) >= 0 ? (uint32_t)((krow + kr0) * (DPK * 2) + kc0 * 16) : OOB);
+            kreg1 = buf_load16(rs_k, (k1ok && (krow + kr1) >= 0) ? (uint32_t)((krow + kr1) * (DPK * 2) + kc1 * 16) : OOB);
+            const int c = vcol + vc0 * 8;
+            const bool cok = c >= 0 && c < LP;
+            vreg0 = buf_load16(rs_v, cok ? (uint32_t)((vr0 * LP + c) * 2) : OOB);
+            vreg1 = buf_load16(rs_v, (v1ok && cok) ? (uint32_t)((vr1 * LP + c) * 2) : OOB);
+        };
+        auto store_unit = [&](int bufi) {
+            char* Vs = smem + bufi * BUF;
+            char* Ks = Vs + VBYTES;
+            const uint32_t one = (uint32_t)E::fromf(1.0f);
+            if (kc0 == D / 8) kreg0.x = (kreg0.x & 0xffff0000u) | one;      // K[:, 40] = 1: the pad column that carries -m_ref
+            if (kc1 == D / 8) kreg1.x = (kreg1.x & 0xffff0000u) | one;
+            *reinterpret_cast<uint4*>(Ks + kr0 * KSTR + kc0 * 16) = kreg0;
+            if (k1ok) *reinterpret_cast<uint4*>(Ks + kr1 * KSTR + kc1 * 16) = kreg1;
+            *reinterpret_cast<uint4*>(Vs + vr0 * VSTR + vc0 * 16) = vreg0;
+            if (v1ok) *reinterpret_cast<uint4*>(Vs + vr1 * VSTR + vc0 * 16) = vreg1;
+        };
+
+        // ---- LDS-DMA staging: 11 wave-instructions per unit (6 KB of K = 6, 5 KB of V^T = 5), instruction q = wave + 4 i ----
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const v4i_t ds_k = raw_rsrc(kbase, (uint32_t)L * DPK * 2), ds_v = raw_rsrc(vbase, (uint32_t)D * LP * 2);
+        const uint32_t smem_base = (uint32_t)(uintptr_t)smem;          // LDS byte address of the dynamic region
+        int dsrc[3];                 // byte offset of this lane's piece inside K / V^T for unit 0
+        bool dneg[3];                // V^T pieces that lie before column 0 in unit 0 (K rows before row 0 in unit -1)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int qi = wv + 4 * i;
+            if (qi < 6) {
+                const int sl = 64 * qi + lane, r = sl / 6, cs = sl % 6, c = (cs + 6 - 3 * ((r >> 3) & 1)) % 6;
+                dsrc[i] = (32 + r) * (DPK * 2) + c * 16;
+                dneg[i] = r < 32;                                // unit -1: rows 64 u + 32 + r = r - 32
+            } else {
+                const int sl = 64 * (qi - 6) + lane, dd = sl >> 3, ch = (sl & 7) ^ ((dd >> 1) & 7);
+                dsrc[i] = (dd * LP + ch * 8 - 32) * 2;
+                dneg[i] = ch < 4;                                // unit 0: columns ch * 8 - 32 .. < 0
+            }
+        }
+        auto dma_unit = [&](int u, int bufi) {     // u >= 1 inside the loop: no range logic at all (rows / columns past the end read 0)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int qi = wv + 4 * i;
+                if (qi >= 11) continue;
+                const bool isk = qi < 6;
+                const bool bad = isk ? (u < 0 && dneg[i]) : (u <= 0 && (u < 0 || dneg[i]));
+                const uint32_t off = bad ? OOB : (uint32_t)(dsrc[i] + u * (isk ? KT * DPK * 2 : KT * 2));
+                const uint32_t dst = smem_base + bufi * BUF_D + (isk ? VBYTES_D + 1024 * qi : 1024 * (qi - 6));
+                dma16(isk ? ds_k : ds_v, dst, off);
+            }
+        };
+
+        f32x16 sa[2], sb[2];
+        uint4 pa[2][2], pb[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) pb[qb][g] = make_uint4(0, 0, 0, 0);      // P of "block -1"
+
+        // ---- one 32-key step: S_n = QK^T(block j+1), O += V^T P^T(block j-1), P_c = exp2(S_c) (block j) ----
+        // 14 MFMAs (fragment f = 0..2: K chunks -> S_n, f = 3..6: V^T (dt, g) -> O; two query blocks each), 16 "pairs" of
+        // scores (2 exp2 + 1 pack each) and 8 packed max3.  VAR & 1: the interleave is written out slot by slot -- MFMA i,
+        // then the exp2 of pair i+1, the pack of pair i and every other slot a max3 -- and pinned with sched_barrier, with
+        // the LDS fragment reads issued two fragments (four MFMAs) ahead.  Otherwise the three streams are emitted one
+        // after the other and hipcc's scheduler decides.
+        uint4 fr[3];                 // LDS fragment ring: fragment f of a step lives in fr[(R0 + f) % 3]
+        auto step = [&](const char* Vs, auto second_c, int j, f32x16 (&sc)[2], f32x16 (&sn)[2], uint4 (&pc)[2][2],
+                        const uint4 (&pp)[2][2]) {
+            constexpr bool SECOND = decltype(second_c)::value;        // second step of a unit: K block kb = 1, V^T groups 2, 3
+            constexpr int KB = SECOND ? 1 : 0, G0 = SECOND ? 2 : 0, R0 = SECOND ? 1 : 0;
+            const char* Ks = Vs + VBY;
+            auto frag = [&](int f, int kb, int g0) -> uint4 {
+                if ((VAR & 256) && f > 0) f = 0;
+                if (DMA)
+                    return f < 3 ? *reinterpret_cast<const uint4*>(Ks + kb * 32 * KSTR_D + kfd[f])
+                                 : *reinterpret_cast<const uint4*>(Vs + ((f - 3) >> 1) * 32 * VSTR_D + vfd[g0 + ((f - 3) & 1)]);
+                return f < 3 ? *reinterpret_cast<const uint4*>(Ks + kb * 32 * KSTR + kfrag + f * 32)
+                             : *reinterpret_cast<const uint4*>(Vs + ((f - 3) >> 1) * 32 * VSTR + vfrag + (g0 + ((f - 3) & 1)) * 32);
+            };
+            auto mma = [&](int i, const uint4& fa) {
+                const int f = i >> 1, qb = i & 1;
+                if (f < 3) { if (!(VAR & 64) || f == 0) sn[qb] = E::mfma(fa, qf[qb][f], f == 0 ? zero16 : sn[qb]); }
+                else if (!(VAR & 32)) o[qb][(f - 3) >> 1] = E::mfma(fa, pp[qb][(f - 3) & 1], o[qb][(f - 3) >> 1]);
+            };
+            auto exp_pair = [&](int pr) {
+                const int qb = pr >> 3, r0 = 2 * (pr & 7);
+                if (VAR & 4) return;
+                sc[qb][r0] = __builtin_amdgcn_exp2f(sc[qb][r0]);
+                sc[qb][r0 + 1] = __builtin_amdgcn_exp2f(sc[qb][r0 + 1]);
+            };
+            auto word = [&](int w) -> uint32_t& {                    // packed word w = 0..15: (qb, g, component)
+                uint4& v = pc[w >> 3][(w >> 2) & 1];
+                return (w & 3) == 0 ? v.x : (w & 3) == 1 ? v.y : (w & 3) == 2 ? v.z : v.w;
+            };
+            auto cvt_pair = [&](int pr) {
+                const int qb = pr >> 3, r0 = 2 * (pr & 7);
+                word(pr) = E::pack2(sc[qb][r0], sc[qb][r0 + 1]);
+            };
+            uint32_t mq[2] = {0u, 0u};
+            if (VAR & 1) {
+                if (!SECOND) {       // (the second step's first two fragments were read during the first step's last slots)
+                    fr[0] = frag(0, KB, G0);
+                    fr[1] = frag(1, KB, G0);
+                }
+                exp_pair(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 14; ++i) {
+                    if ((i & 1) == 0) {
+                        const int f2 = (i >> 1) + 2;
+                        if (f2 <= 6) fr[(R0 + f2) % 3] = frag(f2, KB, G0);
+                        else if (!SECOND) fr[f2 % 3] = frag(f2 - 7, 1, 2);       // next step's fragments 0 and 1
+                    }
+                    mma(i, fr[(R0 + (i >> 1)) % 3]);
+                    exp_pair(i + 1);
+                    cvt_pair(i);
+                    if (i & 1) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                exp_pair(15);
+                cvt_pair(14);
+                cvt_pair(15);
+                mq[0] = pk_max3(mq[0], word(14), word(15));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 14; ++i) mma(i, frag(i >> 1, KB, G0));
+#pragma unroll
+                for (int pr = 0; pr < 16; ++pr) exp_pair(pr);
+#pragma unroll
+                for (int pr = 0; pr < 16; ++pr) cvt_pair(pr);
+#pragma unroll
+                for (int w = 0; w < 16; w += 2) mq[(w >> 3) & 1] = pk_max3(mq[(w >> 3) & 1], word(w), word(w + 1));
+            }
+            uint32_t mm = pk_max3(mq[0], mq[1], mq[1]);
+            // pin the speculative exp2 / pack work in THIS basic block: without it hipcc sinks it below the `forced` test
+            // (its results are dead on the exact path) and the MFMAs above lose the VALU work they are meant to hide
+            asm volatile("" : "+v"(mm));
+            const uint32_t top = max(mm & 0xffffu, mm >> 16);
+            const bool forced = (j == 0) || (j * 32 + 32 > L);
+            if (__builtin_expect(forced || __any(top > (uint32_t)E::fromf(__builtin_exp2f(OFFS_THR))), 0)) {
+                // ---- exact path (first block, ragged / past-the-end block, or a score ran past the deferred maximum): the
+                // block's scores are recomputed from K in global memory (L2), with the pad slot as it stands ----
+                const int krow = j * 32 + swap23(col);
+                uint4 kfs[NKT];
+#pragma unroll
+                for (int tk = 0; tk < NKT; ++tk)
+                    kfs[tk] = buf_load16(rs_k, (uint32_t)(krow * (DPK * 2) + tk * 32 + hi * 16));    // rows >= L read as 0
+                if (hi == QPAD_HI) kfs[QPAD_T].x = (kfs[QPAD_T].x & 0xffff0000u) | (uint32_t)E::fromf(1.0f);   // K[:, 40] = 1
+#pragma unroll
+                for (int tk = 0; tk < NKT; ++tk)
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) sc[qb] = E::mfma(kfs[tk], qf[qb][tk], tk == 0 ? zero16 : sc[qb]);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    if (j * 32 + 32 > L) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = j * 32 + 8 * hi + (r & 7) + 16 * (r >> 3);
+                            if (key >= L) sc[qb][r] = -INFINITY;
+                        }
+                    }
+                    float mx = sc[qb][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[qb][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const bool first = (j == 0);
+                    if (first || __any(mx > OFFS_THR)) {
+                        const float want = m_ref[qb] + (first ? mx : fmaxf(mx, 0.f));
+                        const float nref = E::tof(E::fromf(want));          // what the 16-bit Q slot can carry
+                        const float delta = nref - m_ref[qb];
+                        if (!first) {       // on the first block O is still 0 (and delta may be hugely negative: 2^-delta = inf)
+                            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { sc[qb][r] -= delta; sn[qb][r] -= delta; }
+                        m_ref[qb] = nref;
+                        if (hi == QPAD_HI) qf[qb][QPAD_T].x = (qf[qb][QPAD_T].x & 0xffff0000u) | (uint32_t)E::fromf(-nref);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        pc[qb][g].x = E::pack2(__builtin_amdgcn_exp2f(sc[qb][8 * g + 0]), __builtin_amdgcn_exp2f(sc[qb][8 * g + 1]));
+                        pc[qb][g].y = E::pack2(__builtin_amdgcn_exp2f(sc[qb][8 * g + 2]), __builtin_amdgcn_exp2f(sc[qb][8 * g + 3]));
+                        pc[qb][g].z = E::pack2(__builtin_amdgcn_exp2f(sc[qb][8 * g + 4]), __builtin_amdgcn_exp2f(sc[qb][8 * g + 5]));
+                        pc[qb][g].w = E::pack2(__builtin_amdgcn_exp2f(sc[qb][8 * g + 6]), __builtin_amdgcn_exp2f(sc[qb][8 * g + 7]));
+                    }
+                }
+            }
+        };
+
+        // ---- prologue: unit -1 (K block 0 in its second half) -> S_a = QK^T(block 0); unit 0 staged behind it ----
+        if (DMA) {
+            dma_unit(-1, 1);
+            dma_unit(0, 0);
+            dma_wait();
+        } else {
+            load_unit(-1);
+            store_unit(1);
+            load_unit(0);
+        }
+        __syncthreads();
+        {
+            const char* Ks = smem + BUFB + VBY;
+#pragma unroll
+            for (int tk = 0; tk < NKT; ++tk) {
+                const uint4 kf = DMA ? *reinterpret_cast<const uint4*>(Ks + 32 * KSTR_D + kfd[tk])
+                                     : *reinterpret_cast<const uint4*>(Ks + 32 * KSTR + kfrag + tk * 32);
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) sa[qb] = E::mfma(kf, qf[qb][tk], tk == 0 ? zero16 : sa[qb]);
+            }
+        }
+        if (!DMA) store_unit(0);
+        __syncthreads();
+
+        // units 0 .. NUF - 1 hold two real key blocks each; the last unit holds block J - 1 (J odd) and / or only owes the
+        // P.V of block J - 1 ("drain"): handled after the loop so that the loop body has no per-step range logic
+        // (register staging keeps the simpler form: NU full iterations, past-the-end blocks masked to P = 0 on the exact path)
+        const int NUF = DMA ? (J >> 1) : NU;
+        auto iteration_sync = [&]() {
+            if (DMA) dma_wait();                                    // this wave's pieces of the next unit have landed ...
+            if (!(VAR & 8)) __syncthreads();                        // ... and so have everybody else's
+        };
+        for (int u = 0; u < NUF; ++u) {
+            if (DMA) {
+                if (!(VAR & 16)) dma_unit(u + 1, (u + 1) & 1);      // buffer (u+1)&1 was last read in iteration u-1
+            } else if (!(VAR & 16)) load_unit(u + 1);
+            const char* Vs = smem + (u & 1) * BUFB;
+            step(Vs, std::false_type{}, 2 * u, sa, sb, pa, pb);
+            step(Vs, std::true_type{}, 2 * u + 1, sb, sa, pb, pa);
+            if (!DMA && !(VAR & 16)) store_unit((u + 1) & 1);
+            iteration_sync();
+        }
+        if (DMA) {
+            const char* Vs = smem + (NUF & 1) * BUFB;
+            auto drain = [&](int g0, const uint4 (&pp)[2][2]) {      // O += V^T P^T of the last block; nothing left to score
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const uint4 vf = DMA ? *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR_D + vfd[g0 + g])
+                                             : *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR + vfrag + (g0 + g) * 32);
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb) o[qb][dt] = E::mfma(vf, pp[qb][g], o[qb][dt]);
+                    }
+            };
+            if (J & 1) {
+                step(Vs, std::false_type{}, J - 1, sa, sb, pa, pb);
+                drain(2, pa);
+            } else {
+                drain(0, pb);
+            }
+            __syncthreads();          // the next phase restages both buffers
+        }
+
+        // ---- end of phase: normalise; phase 0 of a two-phase row is parked in LDS rounded to the element type (the
+        // reference adds two half-precision SDPA outputs, attention_processor.py:612) and read back by the same lane ----
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float mine = o[qb][L_DT][L_REG];             // accumulator row 40 (the softmax denominator): lanes with hi == L_HI
+            const float other = __shfl_xor(mine, 32);
+            const float lt = (hi == L_HI) ? mine : other;
+            const float inv = ((ph == 1) ? w2 : 1.0f) / lt;
+            uint32_t pk[10];
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {                   // 5 quads of valid head-dim rows per lane: 8 jj + 4 hi + 0..3
+                const int dt = jj >> 2, r0 = 4 * (jj & 3);
+                float v[4];
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) v[e2] = o[qb][dt][r0 + e2] * inv;
+                if (ph == 1) {
+                    const uint2 prev = *reinterpret_cast<const uint2*>(park + (qb * 5 + jj) / 2 * 1024 + ((qb * 5 + jj) & 1) * 8);
+                    v[0] += E::lo(prev.x); v[1] += E::hi(prev.x); v[2] += E::lo(prev.y); v[3] += E::hi(prev.y);
+                }
+                pk[2 * jj] = E::pack2(v[0], v[1]);
+                pk[2 * jj + 1] = E::pack2(v[2], v[3]);
+            }
+            if (ph == 0 && nph == 2) {
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj)
+                    *reinterpret_cast<uint2*>(park + (qb * 5 + jj) / 2 * 1024 + ((qb * 5 + jj) & 1) * 8) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
+            } else {
+                const int q = q0 + qb * 32 + col;
+                if (q < p.N) {
+                    bf16_t* orow = p.out + ((size_t)b * p.N + q) * p.out_ld + h * D;
+#pragma unroll
+                    for (int jj = 0; jj < 5; ++jj)
+                        *reinterpret_cast<uint2*>(orow + 8 * jj + 4 * hi) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
+                }
+            }
+        }
+    }
+}
+
+template <bool F16, int THR, int VAR>
+int launch_attn40(const AttnParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = attn40_kernel<F16, THR, VAR>;
+    constexpr int LDS_BYTES = (VAR & 512) ? 100 * 1024 : (VAR & 128) ? LDS_BYTES_D : 2 * BUF + PARK;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return imd_set_error("attention(d=40): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid((p.N + 255) / 256, p.H, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, p);
+    return imd_check_launch("attention(d=40)");
+}
+
+}  // namespace
+
+// variant: 6 = pipelined kernel, compiler's own interleave; 7 = with the explicit MFMA / VALU interleave hints;
+//          8 = as 7 with the deferred-maximum bound 2^12 instead of 2^8
+int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    switch (variant) {
+        case 6: return h ? launch_attn40<true, 8, 0>(p, s) : launch_attn40<false, 8, 0>(p, s);
+        case 8: return h ? launch_attn40<true, 12, 1>(p, s) : launch_attn40<false, 12, 1>(p, s);
+        case 9:             // LDS-DMA staging: needs the caller's guarantee that K's pad column holds 1.0
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128>(p, s) : launch_attn40<false, 8, 1 | 128>(p, s);
+            return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
+        // timing ablations of variant 7 (WRONG results; tools/attn_bench.py --variants ...)
+        case 10: return launch_attn40<false, 8, 1 | 4>(p, s);         // no exp2
+        case 11: return launch_attn40<false, 8, 1 | 8>(p, s);         // no loop barrier
+        case 12: return launch_attn40<false, 8, 1 | 16>(p, s);        // no loads / LDS stores in the loop
+        case 13: return launch_attn40<false, 8, 1 | 32>(p, s);        // no P.V MFMAs
+        case 14: return launch_attn40<false, 8, 1 | 64>(p, s);        // 2 of 6 QK^T MFMAs
+        case 15: return launch_attn40<false, 8, 1 | 8 | 16>(p, s);    // no barrier, no staging
+        case 16: return launch_attn40<false, 8, 1 | 256>(p, s);       // one LDS fragment read per step
+        case 17: return launch_attn40<false, 8, 1 | 512>(p, s);       // one workgroup per CU
+        case 18: return launch_attn40<false, 8, 1 | 4 | 16 | 256>(p, s);   // MFMAs + pack only
+        case 19: return launch_attn40<false, 8, 1 | 32 | 64 | 16>(p, s);   // 2 MFMAs per step, everything else
+        default: return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
+    }
+}

@@ -69,7 +69,7 @@ int imd_attention(const imd_attn_params* p, void* stream) {
 
 int imd_set_tuning(int knob, int value) {
     switch (knob) {
-        case 0: IMD_REQUIRE(value >= 1 && value <= 9, "set_tuning: attention variant for head dim 40 must be 1..9"); g_attn_qw40 = value; return 0;
+        case 0: IMD_REQUIRE(value >= 1 && value <= 19, "set_tuning: attention variant for head dim 40 must be 1..19 (10..19: timing ablations, wrong results)"); g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
         case 2: g_gemm_flags = value & 31; return 0;
         default: return imd_set_error("set_tuning: unknown knob %d", knob);

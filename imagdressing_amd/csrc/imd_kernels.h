@@ -27,6 +27,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
 bool imd_conv_patch_supported(const ConvGemmParams& p);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
 int imd_launch_attention(const AttnParams& p, hipStream_t s);
+int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s);   // attention_d40.hip: software-pipelined level-0 kernel
 extern int g_attn_qw40;
 extern int g_attn_xcd;
 extern int g_gemm_flags;

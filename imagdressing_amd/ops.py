@@ -64,12 +64,28 @@ def ensure_device(device: torch.device):
 _ws: Dict[Tuple, torch.Tensor] = {}
 
 
-def workspace(tag: str, shape: Sequence[int], dtype, device) -> torch.Tensor:
+def workspace(tag: str, shape: Sequence[int], dtype, device, init=None) -> torch.Tensor:
     key = (tag, tuple(shape), dtype, str(device))
     t = _ws.get(key)
     if t is None:
         t = torch.zeros(tuple(shape), dtype=dtype, device=device)
+        if init is not None:
+            init(t)
         _ws[key] = t
+    return t
+
+
+def k_buffer(shape: Sequence[int], D: int, dtype, device, tag: Optional[str] = None) -> torch.Tensor:
+    """Zeroed K operand [Bk, H, L, DPK] of the attention kernels.  When the head dim leaves pad columns (D = 40 -> DPK = 48)
+    column D is set to 1.0 ONCE: it is the slot through which the deferred row maximum enters the QK^T MFMA
+    (``imd_attn_params.k_pad_one``).  The projection epilogue writes columns [0, D) only, so the 1 persists."""
+    def init(t):
+        if t.shape[-1] > D:
+            t[..., D] = 1.0
+    if tag is not None:
+        return workspace(tag, shape, dtype, device, init=init)
+    t = torch.zeros(tuple(shape), dtype=dtype, device=device)
+    init(t)
     return t
 
 
@@ -242,7 +258,8 @@ ATTN_EVENT_HOOK = None
 
 
 def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=None, scale2=None,
-              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False):
+              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False, k_pad_one=False):
+    """``k_pad_one``: k1 (and k2) came from :func:`k_buffer`, i.e. their pad column D holds 1.0 (see the header)."""
     ensure_device(q.device)
     p = L.AttnParams()
     dt = q.dtype
@@ -256,6 +273,7 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
     p.L2, p.L2P, p.kv2_bdiv = L2, L2P, kv2_bdiv
     p.out_ld = H * D if out_ld is None else out_ld
     p.causal = int(causal)
+    p.k_pad_one = int(bool(k_pad_one))
     hook = ATTN_EVENT_HOOK
     if hook is not None and hook["match"](B=B, H=H, N=N, D=D, L1=L1, L2=L2 if k2 is not None else 0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 1
+#define IMD_ABI_VERSION 2
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -88,6 +88,10 @@ typedef struct imd_attn_params {
     int dtype;
     int flags;           /* filled in by the library (tuning bits) */
     int causal;          /* 1: query i attends keys 0..i of the first key set only (CLIP text encoder); needs k2 == NULL, D != 40 */
+    int k_pad_one;       /* 1: the caller guarantees that pad column D of EVERY K row (k1 and k2) holds 1.0 (D < DPK only, i.e.
+                          * D = 40: the slot through which the deferred row maximum enters the QK^T MFMA).  The kernels that
+                          * stage K through registers write that 1 themselves (0 or 1 in memory are both fine); with the
+                          * guarantee the d = 40 kernel may stage K / V^T by LDS-DMA, which cannot patch data in flight. */
 } imd_attn_params;
 
 typedef struct imd_groupnorm_params {

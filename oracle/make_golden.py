@@ -79,11 +79,12 @@ def set_lora(proc, lw):
 
 
 def spike_tokens(x, ref, spike):
-    """``spike`` = (query token, key token, garment token, factor): scale those rows of x / ref so that, late in the key
-    sequence, some scores jump far above everything seen before (the online-softmax rescale / redo paths of the kernel)."""
+    """``spike`` = (image token, garment token, factor): scale those rows of x / ref so that, late in both key sequences, the
+    scores of MANY query rows jump far above everything seen before (logits of that key have std ``factor`` instead of 1:
+    the online-softmax rescale / redo paths of the kernel).  The factor stays moderate on purpose: a 16-bit Q / K carries
+    a logit of magnitude s only to about s * 2^-11 (fp16), so wilder spikes would measure the element type, not the kernel."""
     if spike:
-        qt, kt, gt, f = spike
-        x[:, qt] *= f
+        kt, gt, f = spike
         x[:, kt] *= f
         ref[:, gt] *= f
     return x, ref
@@ -114,7 +115,7 @@ def hybrid_case(ap, seed, B, N, M, C, heads, scale, rank=0, lora_scale=0.0, stor
         import numpy as np
         rows = np.sort(np.random.default_rng(seed + 99).choice(N, keep_rows, replace=False))
         if spike:
-            rows = np.unique(np.concatenate([rows, [spike[0], spike[1]]]))
+            rows = np.unique(np.concatenate([rows, [spike[0]]]))
         rows = torch.from_numpy(rows)
         cond, uncond = cond[:, rows].clone(), uncond[:, rows].clone()
     case = dict(kind="hybrid", seed=seed, B=B, N=N, M=M, C=C, heads=heads, scale=scale, rank=rank,
@@ -281,7 +282,7 @@ def main_full():
     cases = {
         "hybrid_d40_n4096": hybrid_case(ap, 2000, B=1, N=4096, M=4096, C=320, heads=8, scale=1.0, store_full=False, keep_rows=384),
         "hybrid_d40_spike": hybrid_case(ap, 2100, B=1, N=840, M=700, C=320, heads=8, scale=0.9, store_full=False,
-                                        spike=(777, 801, 650, 12.0), keep_rows=256),
+                                        spike=(801, 650, 4.0), keep_rows=256),
         "cache_d40": cache_case(ap, 2200, B=1, N=200, C=320, heads=8, store_full=False),
         "cache_d80_cross": cache_case(ap, 2300, B=1, N=144, C=640, heads=8, store_full=False, T=16, KD=768),
     }

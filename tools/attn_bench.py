@@ -6,16 +6,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from imagdressing_amd import ops
 
-def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1):
+def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False):
     H = 8
     B = 2 * Bimg
     dpk, dpv = ops.attn_padded_dims(D)
     g = torch.Generator(device="cuda").manual_seed(0)
-    def r(*s): return torch.randn(*s, generator=g, device="cuda").to(dt)
+    def r(*s): return torch.randn(*s, generator=g, device="cuda").to(dt) * (0.0 if zero else 1.0)
     q = torch.zeros(B, H, N, dpk, dtype=dt, device="cuda"); q[..., :D] = r(B, H, N, D) * (D ** -0.5 * math.log2(math.e))
-    k = torch.zeros(B, H, N, dpk, dtype=dt, device="cuda"); k[..., :D] = r(B, H, N, D)
+    k = ops.k_buffer((B, H, N, dpk), D, dt, "cuda"); k[..., :D] = r(B, H, N, D)
     vt = torch.zeros(B, H, dpv, ops.pad64(N), dtype=dt, device="cuda"); vt[:, :, :D, :N] = r(B, H, D, N)
-    kr = torch.zeros(1, H, M, dpk, dtype=dt, device="cuda"); kr[..., :D] = r(1, H, M, D)
+    kr = ops.k_buffer((1, H, M, dpk), D, dt, "cuda"); kr[..., :D] = r(1, H, M, D)
     vr = torch.zeros(1, H, dpv, ops.pad64(M), dtype=dt, device="cuda"); vr[:, :, :D, :M] = r(1, H, D, M)
     s2 = torch.cat([torch.ones(Bimg), torch.zeros(Bimg)]).cuda()
     out = torch.empty(B, N, H * D, dtype=dt, device="cuda")
@@ -23,7 +23,7 @@ def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1):
         ops.L.check(ops.L.load().imd_set_tuning(0, qw))
     ops.L.check(ops.L.load().imd_set_tuning(1, xcd))
     def go():
-        ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B)
+        ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B, k_pad_one=True)
     for _ in range(3): go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -42,6 +42,7 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only-l0", action="store_true")
     ap.add_argument("--variants", default="", help="comma list of knob-0 values to A/B on the level-0 shape")
+    ap.add_argument("--zero", action="store_true", help="all-zero Q/K/V: same instruction stream, far fewer toggling bits (clock / power probe)")
     ap.add_argument("--default-only", action="store_true", help="level-0 shape with the library's default knobs only (PMC passes)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -54,5 +55,5 @@ if __name__ == "__main__":
         cases += [(80, 1024, 1024, 4, None, 1), (80, 1024, 1024, 4, None, 0), (160, 256, 256, 4, None, 1), (160, 64, 64, 4, None, 1)]
     for rep in range(2):          # interleaved repeats: within-run A/B
         for D, N, M, Bi, qw, xcd in cases:
-            print(json.dumps(run(D, N, M, Bi, a.iters, dt, qw, xcd)), flush=True)
+            print(json.dumps(dict(run(D, N, M, Bi, a.iters, dt, qw, xcd, a.zero), zero=a.zero)), flush=True)
     ops.L.load().imd_set_tuning(0, 1); ops.L.load().imd_set_tuning(1, 1)

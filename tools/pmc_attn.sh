@@ -10,6 +10,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA
   timeout 120 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pass$i -o a -- python $R/tools/attn_bench.py --default-only --iters 2 > $R/$OUT/pass$i.out 2>&1
 done
 cd $R
-python tools/pmc_summary.py $OUT attn_kernel > $OUT/summary.txt 2>&1
+python tools/pmc_summary.py $OUT "${2:-attn}" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 find $OUT -name "*.csv" -size +2000k -delete
