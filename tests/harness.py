@@ -34,7 +34,7 @@ def ref_weights(names, boc, seed):
 
 
 def build_pair(cfg=None, seed=0, device="cuda", kind="refs", ref_seed=7, with_controlnet=False, cross_dim=None,
-               dtype=torch.bfloat16):
+               dtype=torch.bfloat16, rank=16):
     """-> dict(oracle_unet, engine_unet, oracle_ref_unet, engine_ref_unet[, controlnets])
     with processors installed on both sides carrying identical weights."""
     from imagdressing_amd.adapter import attention_processor as AP
@@ -66,17 +66,17 @@ def build_pair(cfg=None, seed=0, device="cuda", kind="refs", ref_seed=7, with_co
         c = hidden_size_of(n, boc)
         if n.endswith("attn1.processor"):
             if kind == "ipa":
-                op, ep = OP.LoraRefSAttn(n, c, rank=16, lora_scale=0.2), AP.LoraRefSAttnProcessor2_0(n, c, rank=16, lora_scale=0.2)
-                fill_lora(op, ep, c, c, 16)
+                op, ep = OP.LoraRefSAttn(n, c, rank=rank, lora_scale=0.2), AP.LoraRefSAttnProcessor2_0(n, c, rank=rank, lora_scale=0.2)
+                fill_lora(op, ep, c, c, rank)
             else:
                 op, ep = OP.RefSAttn(n, c), AP.RefSAttnProcessor2_0(n, c)
             with torch.no_grad():
                 for p in (op, ep):
                     p.to_k_ref.weight.copy_(rw[n]["k"]); p.to_v_ref.weight.copy_(rw[n]["v"])
         elif kind == "ipa":
-            op = OP.LoRAIPAttn(c, cd, rank=16, lora_scale=0.2, scale=0.9, num_tokens=4)
-            ep = AP.LoRAIPAttnProcessor2_0(c, cd, rank=16, lora_scale=0.2, scale=0.9, num_tokens=4)
-            fill_lora(op, ep, c, cd, 16)
+            op = OP.LoRAIPAttn(c, cd, rank=rank, lora_scale=0.2, scale=0.9, num_tokens=4)
+            ep = AP.LoRAIPAttnProcessor2_0(c, cd, rank=rank, lora_scale=0.2, scale=0.9, num_tokens=4)
+            fill_lora(op, ep, c, cd, rank)
             kip, vip = torch.randn(c, cd, generator=g) * cd ** -0.5, torch.randn(c, cd, generator=g) * cd ** -0.5
             with torch.no_grad():
                 for p in (op, ep):

@@ -396,6 +396,37 @@ def test_prepare_flow_of_the_reference_script(tmp_path):
     assert img.shape == (1, 3, 128, 128) and torch.isfinite(img).all() and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_pipeline_unipc_10_steps_vs_oracle(dtype):
+    """The paper's sampler (UniPC, supplementary p.1; /root/reference/app.py:28) through the HIP pipeline for 10 steps against
+    the reference loop semantics (oracle/pipeline.py: two B = 1 UNet calls per step, custom CFG) driven by oracle/unipc.py,
+    the float64 restatement of the library's ``multistep_uni_p/c_bh_update``.  Same relative bars as the DDIM trajectories."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+    from imagdressing_amd.scheduler import UniPCMultistepScheduler
+    from oracle.pipeline import denoise
+    from oracle.unipc import UniPCOracle
+    p = build_pair(SMALL, seed=0, dtype=dtype)
+    steps, gs = 10, 7.0
+    lat = torch.stack([g(42 + i, 4, 16, 16) for i in range(2)])
+    pe, ne = g(10, 1, 77, 64, scale=0.5), g(11, 1, 77, 64, scale=0.5)
+    cloth = g(12, 2, 16, 64, scale=0.5); refl = g(13, 1, 4, 16, 16)
+    ref = torch.cat([denoise(p["o_unet"], p["o_ref"], UniPCOracle(), lat[i:i + 1], pe, ne, cloth, refl, steps, gs) for i in range(2)])
+    sch = UniPCMultistepScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear")
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           image_encoder=None, ImgProj=lambda h: h, scheduler=sch, safety_checker=None, feature_extractor=None)
+    out = pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=128, height=128,
+               num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=2, prompt_embeds=pe.cuda(),
+               negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(), ref_image_latents=refl.cuda(),
+               latents=lat.cuda(), output_type="latent").images
+    st = err_stats(out, ref); record(f"pipeline_unipc_10_steps[{dtype}]", st)
+    bar = _traj_bar(dtype)
+    assert torch.isfinite(out).all()
+    assert st["max_abs"] < bar["max_abs"] * max(st["ref_std"], 1.0) and st["rel_rms"] < bar["rel_rms"], st
+
+
 @torch.no_grad()
 def test_pipeline_unipc_sampler_small():
     """UniPC through the pipeline == the same coefficient lists applied by hand in fp64 to the same UNet

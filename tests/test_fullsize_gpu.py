@@ -107,6 +107,64 @@ def test_full_width_unet_forward_vs_oracle(full_oracle, dtype):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] at FULL width: IP-Adapter FaceID-Plus tokens + rank-128 LoRA on every attention + pose ControlNet
+# ----------------------------------------------------------------------------------------------------------------
+_IPA_ORACLE = {}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_full_width_ipa_lora_controlnet_pipeline_vs_oracle(dtype):
+    """inference_IMAGdressing_ipa_controlnetpose.py's path at the real SD1.5 widths on a 64x64 latent: LoraRefS (rank 128,
+    folded into the weights) + LoRAIP processors (77 text + 4 face tokens), ControlNet-OpenPose residuals split into the
+    cond / uncond halves, custom CFG (g = 7.0) and DDIM -- two images sharing the garment through TWO denoising steps of the
+    HIP pipeline against the reference loop semantics on the fp32 oracle (oracle/pipeline.py, one image at a time).
+    Bars as for the single full-width UNet forward, relative to the oracle's final latent."""
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline_ipa_controlnet import IMAGDressing_v1
+    from imagdressing_amd.scheduler import DDIMScheduler
+    from oracle.ddim import DDIMOracle
+    from oracle.pipeline import denoise
+    from tests.harness import build_pair, err_stats
+    p = build_pair({}, seed=3, kind="ipa", with_controlnet=True, dtype=dtype, rank=128)
+    steps, gs = 2, 7.0
+    lat = torch.stack([rnd(42 + i, 4, 64, 64) for i in range(2)])
+    pe, ne = rnd(10, 1, 77, 768, scale=0.5), rnd(11, 1, 77, 768, scale=0.5)
+    face_p, face_n = rnd(14, 1, 4, 768, scale=0.5), rnd(15, 1, 4, 768, scale=0.5)
+    cloth = rnd(12, 2, 16, 768, scale=0.5); refl = rnd(13, 1, 4, 64, 64)
+    pose = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(16))
+    if "ref" not in _IPA_ORACLE:       # the fp32 oracle trajectory does not depend on the engine's element type: once per session
+        _IPA_ORACLE["ref"] = torch.cat([
+            denoise(p["o_unet"], p["o_ref"], DDIMOracle(), lat[i:i + 1], torch.cat([pe, face_p], 1), torch.cat([ne, face_n], 1),
+                    cloth, refl, steps, gs, controlnet=p["o_ctrl"], control_image=pose,
+                    prompt_embeds_control=torch.cat([ne, pe]), conditioning_scale=0.8) for i in range(2)])
+    ref = _IPA_ORACLE["ref"]
+    for k in ("o_unet", "o_ref", "o_ctrl"):
+        p[k] = None
+
+    class FaceProj:      # image_proj_model stand-in returning the given face tokens
+        def __call__(self, idv, clip):
+            return (face_p if float(idv.abs().sum()) > 0 else face_n).cuda()
+    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                        clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           controlnet=p["e_ctrl"], image_encoder=None, ImgProj=lambda h: h, ip_ckpt=None, scheduler=sch)
+    pipe.image_proj_model = FaceProj()
+    out = pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=512, height=512,
+               num_inference_steps=steps, guidance_scale=gs, pose_image=pose.cuda(), faceid_embeds=torch.ones(1, 512),
+               face_clip_hidden_states=torch.zeros(1, 257, 1280), face_uncond_clip_hidden_states=torch.zeros(1, 257, 1280),
+               image_scale=1.0, ipa_scale=0.9, s_lora_scale=0.2, c_lora_scale=0.2, controlnet_conditioning_scale=0.8,
+               num_images_per_prompt=2, prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(),
+               ref_clip_hidden_states=cloth[1:2].cuda(), ref_image_latents=refl.cuda(), latents=lat.cuda(), output_type="latent").images
+    st = err_stats(out, ref)
+    assert torch.isfinite(out).all()
+    bar = dict(rel_rms=5e-3, max_rel=2.5e-2) if dtype == torch.float16 else dict(rel_rms=2.5e-2, max_rel=0.15)
+    assert st["rel_rms"] < bar["rel_rms"] and st["max_abs"] < bar["max_rel"] * st["ref_std"], st
+    assert (ref[0] - ref[1]).pow(2).mean().sqrt() > 0.2 * ref.std()         # two different images
+    del pipe, p
+    torch.cuda.empty_cache()
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # the BASELINE configs[1] pipeline: determinism, batched == sharded generation
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "f16"])

@@ -289,3 +289,45 @@ def test_unipc_order1_is_ddim_and_constant_prediction_is_exact():
     ts = [int(t) for t in s50.timesteps]
     assert ts[0] == 999 and ts[-1] == 20 and len(ts) == 50 and all(a > b for a, b in zip(ts, ts[1:]))
     assert abs(s50._sig[-1] - ((1 - float(s50._ac[0])) / float(s50._ac[0])) ** 0.5) < 1e-12
+
+
+def test_unipc_coefficient_lists_equal_the_library_form_oracle():
+    """imagdressing_amd.scheduler.UniPCMultistepScheduler (flat coefficient lists, applied by one fused launch each) against
+    oracle/unipc.py (the library's own tensor-form update functions, float64) over whole 10- and 25-step trajectories with a
+    nonlinear, state-dependent epsilon model -- orders 1 to 3, corrector on, lower_order_final as the library defaults."""
+    import numpy as np
+    import torch
+    from oracle.unipc import UniPCOracle
+    rng = np.random.default_rng(3)
+    W = rng.standard_normal((6, 6)) * 0.4
+
+    def eps_model(x, pos):           # smooth, nonlinear in x, different at every step
+        return np.tanh(x @ W + 0.1 * pos) + 0.05 * x
+    for order in (1, 2, 3):
+        for N in (10, 25):
+            x0 = rng.standard_normal((2, 6))
+            orc = UniPCOracle(solver_order=order)
+            ts = orc.set_timesteps(N)
+            xo = torch.from_numpy(x0.copy())
+            x = x0.copy()
+            sch, _ = _unipc_run(order, N, True, 0, None, x, lower_order_final=True)
+            assert [int(t) for t in sch.timesteps] == [int(t) for t in ts]
+            for pos in range(N):
+                xo = orc.step(torch.from_numpy(eps_model(xo.numpy(), pos)), ts[pos], xo)
+                # the same update sequence `_advance` performs, on numpy vectors (see _unipc_run)
+                named = {"x": x, "eps": eps_model(x, pos)}
+                mt = sum(c * named[n] for c, n in sch.x0_terms(pos))
+                sch.step_index = pos
+                hist = {f"m{k}": m for k, m in enumerate(reversed(sch.model_outputs))}
+                if pos > 0 and sch.last_sample is not None:
+                    d = dict(hist, x=sch.last_sample, mt=mt)
+                    x = sum(c * d[n] for c, n in sch.corrector_terms(pos, sch.this_order))
+                sch.model_outputs = (sch.model_outputs + [mt])[-order:]
+                sch.ts_hist = (sch.ts_hist + [pos])[-order:]
+                sch.this_order = sch._order_now()
+                sch.last_sample = x
+                hist = {f"m{k}": m for k, m in enumerate(reversed(sch.model_outputs))}
+                x = sum(c * dict(hist, x=x)[n] for c, n in sch.predictor_terms(pos, sch.this_order))
+                if sch.lower_order_nums < order:
+                    sch.lower_order_nums += 1
+                assert np.allclose(x, xo.numpy(), rtol=1e-9, atol=1e-10), (order, N, pos, np.abs(x - xo.numpy()).max())
