@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     const int cpix = kColPix[col];             // pixel (0..31) this lane's MFMA column stands for
 
     const int H = p.Hin, W = p.Win;
-    const int tiles_x = W / TW, tiles_y = H / TH;
+    // ragged maps (96 x 72 latents of the 768 x 576 configuration: W = 72, 36, 18): the last tile row / column hangs over the
+    // edge; its patch pixels outside the image read as zero like any halo pixel and its output pixels are not stored
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const int n_tiles = (p.N + BN - 1) / BN;
     int bid, tile_n;
     xcd_tile_order(p.flags, (int)(gridDim.x / n_tiles), n_tiles, bid, tile_n);      // bid = pixel-tile index
@@ -245,9 +247,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
         for (int ch = tid; ch < CHUNKS; ch += 256) {
             const int row = ch / CPR, cc = (ch - row * CPR) * 8;
             const int q = wr * EROWS + row;
-            const int m = (b * H + y0 + q / TW) * W + x0 + q % TW;
+            const int oy = y0 + q / TW, ox = x0 + q % TW;
+            const int m = (b * H + oy) * W + ox;
             const int n = n0 + cc;
-            if (n >= p.N) continue;
+            if (n >= p.N || oy >= H || ox >= W) continue;
             const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
             const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
             if (slab) {
@@ -266,12 +269,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 }  // namespace
 
 bool imd_conv_patch_supported(const ConvGemmParams& p) {
-    return p.taps == 9 && p.stride == 1 && !p.ups && !p.pad_br_only && p.Hin == p.Hout && p.Win == p.Wout && (p.Hin % TH) == 0 &&
-           (p.Win % TW) == 0 && (p.Cin % CK) == 0 && p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU;
+    return p.taps == 9 && p.stride == 1 && !p.ups && !p.pad_br_only && p.Hin == p.Hout && p.Win == p.Wout && p.Hin >= TH &&
+           p.Win >= TW && (p.Cin % CK) == 0 && p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU;
 }
 
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
-    if (!imd_conv_patch_supported(p)) return imd_set_error("conv_patch: unsupported geometry (needs 3x3 stride 1, H %% 8 == 0, W %% 16 == 0, Cin %% 32 == 0)");
+    if (!imd_conv_patch_supported(p)) return imd_set_error("conv_patch: unsupported geometry (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 32 == 0)");
     static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     const void* kern = h ? reinterpret_cast<const void*>(conv3x3_patch_kernel<true>) : reinterpret_cast<const void*>(conv3x3_patch_kernel<false>);
@@ -281,7 +284,7 @@ int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
         attr_set[h] = true;
     }
     const int B = p.M / (p.Hout * p.Wout);
-    const long blocks = (long)B * (p.Hin / TH) * (p.Win / TW) * ((p.N + BN - 1) / BN);
+    const long blocks = (long)B * ((p.Hin + TH - 1) / TH) * ((p.Win + TW - 1) / TW) * ((p.N + BN - 1) / BN);
     if (h) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
     else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
     return imd_check_launch("conv_patch");

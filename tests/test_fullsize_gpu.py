@@ -165,6 +165,59 @@ def test_full_width_ipa_lora_controlnet_pipeline_vs_oracle(dtype):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4] geometry at FULL width: ControlNet-inpainting at 768 x 576 (latent 96 x 72, N = 6912 / 1728 / 432 / 108)
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_full_width_inpaint_768x576_pipeline_vs_oracle(dtype):
+    """inference_IMAGdressing_controlnetinpainting.py's path at the real widths and the real geometry: level-0 hybrid attention
+    over N = M = 6912 tokens (108 key blocks: the d = 40 kernel's odd / ragged-unit tail), 3x3 convolutions on 96 x 72, 48 x 36,
+    24 x 18 and 12 x 9 maps (ragged halo-patch tiles), ControlNet residuals, custom CFG (g = 5.0), DDIM and the per-step
+    masked blend with the re-noised original latents -- one image, two steps, against the reference loop on the fp32 oracle."""
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline_controlnet_inpainting import IMAGDressing_v1
+    from imagdressing_amd.scheduler import DDIMScheduler
+    from oracle.ddim import DDIMOracle
+    from oracle.pipeline import denoise
+    from tests.harness import build_pair, err_stats
+    p = build_pair({}, seed=5, with_controlnet=True, dtype=dtype)
+    steps, gs = 2, 5.0
+    h, w = 96, 72
+    noise = rnd(42, 1, 4, h, w)
+    pe, ne = rnd(10, 1, 77, 768, scale=0.5), rnd(11, 1, 77, 768, scale=0.5)
+    cloth = rnd(12, 2, 16, 768, scale=0.5); refl = rnd(13, 1, 4, h, w)
+    img_lat = rnd(17, 1, 4, h, w)
+    mask = torch.zeros(1, 1, h, w); mask[:, :, 18:78, 13:59] = 1.0                # centred rectangle, 40 % of the area
+    ctrl = torch.rand(1, 3, 8 * h, 8 * w, generator=torch.Generator().manual_seed(18))
+    if "ref" not in _INPAINT_ORACLE:
+        _INPAINT_ORACLE["ref"] = denoise(p["o_unet"], p["o_ref"], DDIMOracle(), noise, pe, ne, cloth, refl, steps, gs,
+                                         controlnet=p["o_ctrl"], control_image=ctrl, prompt_embeds_control=torch.cat([ne, pe]),
+                                         inpaint=dict(mask=mask, image_latents=img_lat, noise=noise))
+    ref = _INPAINT_ORACLE["ref"]
+    for k in ("o_unet", "o_ref", "o_ctrl"):
+        p[k] = None
+    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                        clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           controlnet=p["e_ctrl"], image_encoder=None, ImgProj=lambda x: x, scheduler=sch)
+    out = pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=8 * w, height=8 * h,
+               num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=1, control_image=ctrl.cuda(),
+               prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(),
+               ref_image_latents=refl.cuda(), image_latents=img_lat.cuda(), mask_latents=mask.cuda(), noise=noise.cuda(),
+               output_type="latent").images
+    st = err_stats(out, ref)
+    assert torch.isfinite(out).all() and tuple(out.shape) == (1, 4, h, w)
+    bar = dict(rel_rms=5e-3, max_rel=2.5e-2) if dtype == torch.float16 else dict(rel_rms=2.5e-2, max_rel=0.15)
+    assert st["rel_rms"] < bar["rel_rms"] and st["max_abs"] < bar["max_rel"] * st["ref_std"], st
+    keep = (mask == 0).expand(1, 4, -1, -1)       # outside the mask: exactly the original latents after the last step (:494-500)
+    assert torch.allclose(out.cpu()[keep], img_lat[keep], atol=1e-5)
+    del pipe, p
+    torch.cuda.empty_cache()
+
+
+_INPAINT_ORACLE = {}
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # the BASELINE configs[1] pipeline: determinism, batched == sharded generation
 # ----------------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "f16"])

@@ -141,7 +141,9 @@ def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups, dt):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,split", [
     (2, 16, 16, 64, 64, 1), (1, 8, 32, 32, 320, 1), (3, 24, 16, 96, 132, 1), (1, 32, 32, 320, 320, 1), (2, 16, 16, 640, 256, 4),
-    (1, 8, 16, 1280, 128, 8)])
+    (1, 8, 16, 1280, 128, 8),
+    # ragged maps: tiles hang over the right / bottom edge (the 96 x 72 latent of BASELINE configs[4] and its 48 x 36 level)
+    (1, 96, 72, 320, 320, 1), (2, 48, 36, 640, 640, 2), (1, 12, 18, 64, 64, 1), (2, 9, 17, 32, 40, 1)])
 @DTS
 def test_conv3x3_halo_patch(ops, B, H, W, Cin, Cout, split, dt):
     """tile config 5 (LDS-resident halo patch) == F.conv2d, with the full epilogue and with K slices"""

@@ -15,14 +15,12 @@ SPLITS = [1, 2, 3, 4, 6, 8]
 
 
 def collect_shapes(args, dt):
-    import bench
-    a = argparse.Namespace(batch=args.batch, res=args.res, ddim_steps=1, dtype=args.dtype)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import configs
     dev = torch.device("cuda", 0)
-    pipe = bench.build_pipeline(dev, dt, 0)
-    inp = bench.synthetic_inputs(a, dev, dt, 0, 1)
+    pipe, kw = configs.build(args.config, dev, dt, args.batch or None, steps=1)
     ops.GEMM_TRACE = []
-    pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=args.res, height=args.res,
-         num_inference_steps=1, guidance_scale=7.5, num_images_per_prompt=args.batch, output_type="latent", **inp)
+    pipe(**kw)
     torch.cuda.synchronize()
     tr, ops.GEMM_TRACE = ops.GEMM_TRACE, None
     del pipe
@@ -58,8 +56,12 @@ def time_candidate(t, cfg, split, dt, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--config", type=int, default=1, help="BASELINE configuration whose shapes are tuned: 1 (bench line), 3 (IPA + "
+                    "ControlNet, batch 8), 5 (768x576 inpainting + ControlNet, 4 images); see tools/configs.py")
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--merge", action="store_true", help="start from the shipped table and add / overwrite only the traced shapes")
+    ap.add_argument("--skip-known", action="store_true", help="with --merge: leave shapes that the shipped table already holds alone")
+    ap.add_argument("--quick", action="store_true", help="one repeat, K splits {1, 2, 4}")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--out", default="gpurun_out/gemm_tuning.json")
@@ -70,6 +72,12 @@ def main():
     shapes = collect_shapes(args, dt)
     result, log = {}, []
     cfgs = CFGS
+    splits = [1, 2, 4] if args.quick else SPLITS
+    if args.merge:
+        with open(os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "gemm_tuning.json")) as f:
+            result = json.load(f).get("shapes", {})
+        if args.skip_known:
+            shapes = {k: t for k, t in shapes.items() if k not in result}
     if args.only_conv3x3:
         with open(os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "gemm_tuning.json")) as f:
             result = json.load(f).get("shapes", {})
@@ -80,9 +88,9 @@ def main():
         flops = 2.0 * t["M"] * t["N"] * t["K"]
         cands = {}
         ktiles = (t["K"] + 63) // 64
-        for rep in range(2):
+        for rep in range(1 if args.quick else 2):
             for cfg in cfgs:
-                for split in SPLITS:
+                for split in splits:
                     if split > 1 and (ktiles // split < 8 or not t["any_splittable"]):
                         continue
                     try:
@@ -102,7 +110,7 @@ def main():
         print(json.dumps(log[-1]), flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
-        json.dump(dict(note="measured by tools/gemm_tune.py on MI355X", batch=args.batch, res=args.res, dtype=args.dtype,
+        json.dump(dict(note="measured by tools/gemm_tune.py on MI355X", config=args.config, batch=args.batch, dtype=args.dtype,
                        shapes=result, log=log, total_us_heuristic=round(total_before, 1), total_us_tuned=round(total_after, 1)), f, indent=1)
     print("total per traced pass: heuristic %.1f us -> tuned %.1f us" % (total_before, total_after))
 
