@@ -174,6 +174,27 @@ def _project_kv(tokens: torch.Tensor, wkv: torch.Tensor, heads: int):
     return k, vt, Lk, LP
 
 
+_FP8_KV: Dict[int, tuple] = {}
+
+
+def _fp8_kv(kv, cache: bool):
+    """e4m3 versions of a (K, V^T, L, LP) pair; step-invariant pairs (garment / text K/V) are quantised once (the cache holds
+    the 16-bit source too, so an address cannot be recycled under it)."""
+    k, vt = kv[0], kv[1]
+    e = ops.FP8_EXPS
+    if cache:
+        hit = _FP8_KV.get(id(k))
+        if hit is not None and hit[0] is k and hit[1] == (e["q"], e["k"], e["v"]):
+            return hit[2], hit[3]
+    k8 = ops.quantize_fp8_rows(k, e["k"], pad_val=float(2 ** (e["q"] + e["k"])))
+    v8 = ops.quantize_fp8_vt(vt, e["v"])
+    if cache:
+        if len(_FP8_KV) > 64:
+            _FP8_KV.clear()
+        _FP8_KV[id(k)] = (k, (e["q"], e["k"], e["v"]), k8, v8)
+    return k8, v8
+
+
 def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, self_attn: bool,
                      kv1=None, kv1_bdiv: int = 1, kv2=None, kv2_bdiv: int = 1, scale2: Optional[torch.Tensor] = None,
                      wo: torch.Tensor, bo: Optional[torch.Tensor], residual: Optional[torch.Tensor]) -> torch.Tensor:
@@ -196,6 +217,17 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
         ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1,
                       heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale)]))
     o = torch.empty(B, N, Cc, dtype=dt, device=dev)
+    if ops.ATTN_FP8 and D == 40:            # BASELINE configs[4]: level-0 attention on the MX-FP8 MFMA (opt-in)
+        e = ops.FP8_EXPS
+        q8 = ops.quantize_fp8_rows(q, e["q"])
+        k18, v18 = _fp8_kv(kv1, cache=not self_attn)
+        kw = {}
+        if kv2 is not None and scale2 is not None:
+            k28, v28 = _fp8_kv(kv2, cache=True)
+            kw = dict(k2=k28, v2t=v28, L2=kv2[2], L2P=kv2[3], kv2_bdiv=kv2_bdiv, scale2=scale2)
+        ops.attention_fp8(q8, k18, v18, o, B=B, H=heads, N=N, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, **kw)
+        res2 = None if residual is None else residual.view(B * N, Cc)
+        return ops.linear(o.view(B * N, Cc), wo, bo, res=res2).view(B, N, Cc)
     kw = {}
     if kv2 is not None and scale2 is not None:
         kw = dict(k2=kv2[0], v2t=kv2[1], L2=kv2[2], L2P=kv2[3], kv2_bdiv=kv2_bdiv, scale2=scale2)

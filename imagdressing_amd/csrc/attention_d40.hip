@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
 // VAR bit 0: MFMA / VALU interleave written out and pinned   bit 1: plain (not XCD-aware) work order
 // ABLATION bits (timing experiments only, results are WRONG): 4: exp2 replaced by a move   8: no barrier in the loop
 //   16: no global loads / LDS stores in the loop   32: no P.V MFMAs   64: no QK^T MFMAs   256: one LDS fragment read per step
-//   512: 100 KB of LDS per workgroup (one workgroup = one wave per SIMD)
+//   512: 100 KB of LDS per workgroup (one workgroup = one wave per SIMD)   2048: no packed-max / overflow test
 template <bool F16, int THR, int VAR>
 __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
     using E = El<F16>;
@@ -302,13 +302,13 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                     mma(i, fr[(R0 + (i >> 1)) % 3]);
                     exp_pair(i + 1);
                     cvt_pair(i);
-                    if (i & 1) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
+                    if ((i & 1) && !(VAR & 2048)) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 exp_pair(15);
                 cvt_pair(14);
                 cvt_pair(15);
-                mq[0] = pk_max3(mq[0], word(14), word(15));
+                if (!(VAR & 2048)) mq[0] = pk_max3(mq[0], word(14), word(15));
             } else {
 #pragma unroll
                 for (int i = 0; i < 14; ++i) mma(i, frag(i >> 1, KB, G0));
@@ -520,6 +520,7 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
         case 17: return launch_attn40<false, 8, 1 | 512>(p, s);       // one workgroup per CU
         case 18: return launch_attn40<false, 8, 1 | 4 | 16 | 256>(p, s);   // MFMAs + pack only
         case 19: return launch_attn40<false, 8, 1 | 32 | 64 | 16>(p, s);   // 2 MFMAs per step, everything else
+        case 20: return launch_attn40<false, 8, 1 | 128 | 2048>(p, s);     // LDS-DMA variant without the packed-max / overflow test
         default: return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
     }
 }

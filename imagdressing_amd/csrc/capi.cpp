@@ -67,9 +67,26 @@ int imd_attention(const imd_attn_params* p, void* stream) {
     return imd_launch_attention(*p, (hipStream_t)stream);
 }
 
+int imd_attention_fp8(const imd_attn_params* p, int eq, int ek, int ev, void* stream) {
+    IMD_REQUIRE(p != nullptr, "attention_fp8: null params");
+    IMD_REQUIRE(p->q && p->k1 && p->v1t && p->out, "attention_fp8: null q/k/v/out pointer");
+    IMD_REQUIRE((p->k2 == nullptr) == (p->v2t == nullptr), "attention_fp8: k2 and v2t must be given together");
+    IMD_REQUIRE(p->out_ld >= p->H * p->D && p->out_ld % 4 == 0, "attention_fp8: bad out_ld %d", p->out_ld);
+    IMD_REQUIRE(p->dtype == IMD_DTYPE_BF16 || p->dtype == IMD_DTYPE_F16, "attention_fp8: unknown output dtype %d", p->dtype);
+    return imd_launch_attention_fp8(*p, eq, ek, ev, (hipStream_t)stream);
+}
+
+int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long count, int LP, int exp2_scale, float pad_val, int dtype,
+                          void* stream) {
+    IMD_REQUIRE(src && dst && count > 0, "attn_quantize_fp8: null pointer / empty");
+    IMD_REQUIRE(kind == 0 || kind == 1, "attn_quantize_fp8: kind must be 0 (Q / K rows) or 1 (V^T)");
+    IMD_REQUIRE(exp2_scale >= -16 && exp2_scale <= 16, "attn_quantize_fp8: exponent out of range");
+    return imd_launch_attn_quantize_fp8(src, dst, kind, count, LP, exp2_scale, pad_val, dtype, (hipStream_t)stream);
+}
+
 int imd_set_tuning(int knob, int value) {
     switch (knob) {
-        case 0: IMD_REQUIRE(value >= 1 && value <= 19, "set_tuning: attention variant for head dim 40 must be 1..19 (10..19: timing ablations, wrong results)"); g_attn_qw40 = value; return 0;
+        case 0: IMD_REQUIRE(value >= 1 && value <= 20, "set_tuning: attention variant for head dim 40 must be 1..20 (10..20: timing ablations, wrong results)"); g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
         case 2: g_gemm_flags = value & 31; return 0;
         default: return imd_set_error("set_tuning: unknown knob %d", knob);

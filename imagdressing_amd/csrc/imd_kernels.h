@@ -27,7 +27,10 @@ int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
 bool imd_conv_patch_supported(const ConvGemmParams& p);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
 int imd_launch_attention(const AttnParams& p, hipStream_t s);
-int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s);   // attention_d40.hip: software-pipelined level-0 kernel
+int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s);
+int imd_launch_attention_fp8(const AttnParams& p, int eq, int ek, int ev, hipStream_t s);                       // attention_d40_fp8.hip
+int imd_launch_attn_quantize_fp8(const bf16_t* src, unsigned char* dst, int kind, long rows_or_groups, int LP, int exp2_scale,
+                                 float pad_val, int dtype, hipStream_t s);   // attention_d40.hip: software-pipelined level-0 kernel
 extern int g_attn_qw40;
 extern int g_attn_xcd;
 extern int g_gemm_flags;

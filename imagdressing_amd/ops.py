@@ -286,6 +286,56 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# MX-FP8 attention (BASELINE.json configs[4]: "... with fp8 MFMA attention"): opt-in, head dim 40 (UNet level 0) only
+# ---------------------------------------------------------------------------------------------------------------------
+ATTN_FP8 = False                       # processors route d = 40 attention through imd_attention_fp8 when set
+FP8_EXPS = dict(q=4, k=2, v=3)         # operands are stored as value * 2^e in e4m3 (range 2^-9 .. 448); eq + ek <= 8
+
+
+def quantize_fp8_rows(x: torch.Tensor, exp: int, pad_val: float = 0.0) -> torch.Tensor:
+    """Q or K [.., L, 48] 16-bit -> e4m3 bytes [.., L, 64] (columns 0..39 * 2^exp, columns 40 / 41 = pad_val)."""
+    ensure_device(x.device)
+    if x.shape[-1] != 48:
+        raise L.ImdError(f"quantize_fp8_rows: expected head-dim-40 rows padded to 48, got {tuple(x.shape)}")
+    rows = x.numel() // 48
+    out = torch.empty(x.shape[:-1] + (64,), dtype=torch.uint8, device=x.device)
+    L.check(L.load().imd_attn_quantize_fp8(_dev(x, x.dtype, "x"), out.data_ptr(), 0, rows, 0, exp, float(pad_val), _code(x, "x"), _stream()))
+    return out
+
+
+def quantize_fp8_vt(vt: torch.Tensor, exp: int) -> torch.Tensor:
+    """V^T [.., 64, LP] 16-bit -> e4m3 bytes [.., 64, LP] (rows 0..39), keys permuted inside 64-groups as the kernel expects."""
+    ensure_device(vt.device)
+    if vt.shape[-2] != 64 or vt.shape[-1] % 64:
+        raise L.ImdError(f"quantize_fp8_vt: expected [.., 64, LP] with LP % 64 == 0, got {tuple(vt.shape)}")
+    LP = vt.shape[-1]
+    groups = vt.numel() // (64 * LP)
+    out = torch.zeros(vt.shape, dtype=torch.uint8, device=vt.device)
+    L.check(L.load().imd_attn_quantize_fp8(_dev(vt, vt.dtype, "vt"), out.data_ptr(), 1, groups, LP, exp, 0.0, _code(vt, "vt"), _stream()))
+    return out
+
+
+def attention_fp8(q8, k1, v1t, out, *, B, H, N, L1, L1P, kv1_bdiv=1, k2=None, v2t=None, scale2=None, L2=0, L2P=0, kv2_bdiv=1,
+                  out_ld=None, exps=None):
+    """imd_attention_fp8 on e4m3 operands from quantize_fp8_rows / quantize_fp8_vt (head dim 40); ``out`` is 16-bit."""
+    ensure_device(out.device)
+    e = dict(FP8_EXPS, **(exps or {}))
+    u8 = torch.uint8
+    p = L.AttnParams()
+    p.dtype = _code(out, "out")
+    p.q, p.k1, p.v1t = _dev(q8, u8, "q8"), _dev(k1, u8, "k1"), _dev(v1t, u8, "v1t")
+    p.k2, p.v2t = _opt(k2, u8, "k2"), _opt(v2t, u8, "v2t")
+    p.scale2 = _opt(scale2, torch.float32, "scale2")
+    p.out = _dev(out, out.dtype, "out")
+    p.B, p.H, p.N, p.D = B, H, N, 40
+    p.L1, p.L1P, p.kv1_bdiv = L1, L1P, kv1_bdiv
+    p.L2, p.L2P, p.kv2_bdiv = L2, L2P, kv2_bdiv
+    p.out_ld = H * 40 if out_ld is None else out_ld
+    L.check(L.load().imd_attention_fp8(C.byref(p), e["q"], e["k"], e["v"], _stream()))
+    return out
+
+
 def group_norm(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5, silu=False, out=None) -> torch.Tensor:
     """x [B, HW, C] (or [B, H, W, C]) bf16 NHWC."""
     ensure_device(x.device)

@@ -148,9 +148,23 @@ int imd_conv_gemm_auto_split(int M, int N, int K, int cfg);
  * the single SDPA of CAttnProcessor2_0 (:277-279) / CacheAttnProcessor2_0 (:80-82), and
  * PerceiverAttention's softmax(QK^T)V (adapter/resampler.py:71-74). */
 int imd_attention(const imd_attn_params* p, void* stream);
+/* The same fused dual-softmax attention for head dim 40 on the MX block-scaled FP8 MFMA (BASELINE.json configs[4]: the
+ * 768x576 ControlNet-inpainting configuration "with fp8 MFMA attention").  q / k1 / v1t / k2 / v2t of `p` point to e4m3
+ * operands produced by imd_attn_quantize_fp8 (Q8, K8: [.., rows, 64] bytes; V8^T: [.., 64, LP] bytes, keys permuted inside
+ * groups of 64); `out` and `dtype` are the 16-bit output.  eq / ek / ev: the power-of-two exponents the operands were
+ * scaled by (q * 2^eq ...), 0 <= eq + ek <= 8.  Same reference lines as imd_attention (attention_processor.py:589-612). */
+int imd_attention_fp8(const imd_attn_params* p, int eq, int ek, int ev, void* stream);
+/* 16-bit head-split attention operands -> the e4m3 operands of imd_attention_fp8.
+ * kind 0: Q or K rows [count, 48] -> [count, 64]: columns 0..39 scaled by 2^exp2_scale, columns 40 and 41 = pad_val
+ *         (Q: 0; K: 2^(eq+ek), the slots that carry the deferred row maximum), the rest 0;
+ * kind 1: V^T [count, 64, LP] -> [count, 64, LP] bytes (rows 0..39), scaled by 2^exp2_scale, key k of every 64-group stored
+ *         at position 32 ((k >> 3) & 1) + 8 ((k >> 4) & 3) + (k & 7) (the order the kernel's packed P comes out in). */
+int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long count, int LP, int exp2_scale, float pad_val, int dtype,
+                          void* stream);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
-/* performance knobs (results are identical for every setting).  knob 0: head-dim-40 attention kernel variant (1..4, default 2: two 32-row query blocks per wave, 32-key softmax blocks, speculative exp);
+/* performance knobs (results are identical for every setting).  knob 0: head-dim-40 attention kernel variant (default 9: software-pipelined kernel of attention_d40.hip, LDS-DMA staging when
+ * imd_attn_params.k_pad_one; 7: register staging; 2 / 5: round-1 kernel; 10..19: timing ablations with WRONG results);
  * knob 1: XCD-aware work mapping of the attention grid (0|1);
  * knob 2: GEMM operand-fetch bits (bit0: tap-inner K order for 3x3 convs, bit1: weight loads bypass the L1,
  * bit2: XCD-aware tile order -- each XCD's L2 owns whole row tiles or whole channel tiles, whichever moves fewer bytes;

@@ -167,9 +167,10 @@ def test_full_width_ipa_lora_controlnet_pipeline_vs_oracle(dtype):
 # ----------------------------------------------------------------------------------------------------------------
 # BASELINE configs[4] geometry at FULL width: ControlNet-inpainting at 768 x 576 (latent 96 x 72, N = 6912 / 1728 / 432 / 108)
 # ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fp8", [False, True], ids=["attn16", "attn-fp8"])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @torch.no_grad()
-def test_full_width_inpaint_768x576_pipeline_vs_oracle(dtype):
+def test_full_width_inpaint_768x576_pipeline_vs_oracle(dtype, fp8):
     """inference_IMAGdressing_controlnetinpainting.py's path at the real widths and the real geometry: level-0 hybrid attention
     over N = M = 6912 tokens (108 key blocks: the d = 40 kernel's odd / ragged-unit tail), 3x3 convolutions on 96 x 72, 48 x 36,
     24 x 18 and 12 x 9 maps (ragged halo-patch tiles), ControlNet residuals, custom CFG (g = 5.0), DDIM and the per-step
@@ -178,6 +179,7 @@ def test_full_width_inpaint_768x576_pipeline_vs_oracle(dtype):
     from imagdressing_amd.scheduler import DDIMScheduler
     from oracle.ddim import DDIMOracle
     from oracle.pipeline import denoise
+    from imagdressing_amd import ops as O
     from tests.harness import build_pair, err_stats
     p = build_pair({}, seed=5, with_controlnet=True, dtype=dtype)
     steps, gs = 2, 5.0
@@ -199,14 +201,25 @@ def test_full_width_inpaint_768x576_pipeline_vs_oracle(dtype):
                         clip_sample=False, set_alpha_to_one=False, steps_offset=1)
     pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
                            controlnet=p["e_ctrl"], image_encoder=None, ImgProj=lambda x: x, scheduler=sch)
-    out = pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=8 * w, height=8 * h,
-               num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=1, control_image=ctrl.cuda(),
-               prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(),
-               ref_image_latents=refl.cuda(), image_latents=img_lat.cuda(), mask_latents=mask.cuda(), noise=noise.cuda(),
-               output_type="latent").images
+    O.ATTN_FP8 = fp8            # configs[4] proper: the level-0 (d = 40) hybrid attention on the MX-FP8 MFMA
+    try:
+        out = pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=8 * w, height=8 * h,
+                   num_inference_steps=steps, guidance_scale=gs, num_images_per_prompt=1, control_image=ctrl.cuda(),
+                   prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(),
+                   ref_image_latents=refl.cuda(), image_latents=img_lat.cuda(), mask_latents=mask.cuda(), noise=noise.cuda(),
+                   output_type="latent").images
+    finally:
+        O.ATTN_FP8 = False
     st = err_stats(out, ref)
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/parity_stats.jsonl", "a") as f:
+        f.write(json.dumps(dict(test=f"full_width_inpaint_768x576[{dtype},fp8_attention={fp8}]", **st)) + "\n")
     assert torch.isfinite(out).all() and tuple(out.shape) == (1, 4, h, w)
     bar = dict(rel_rms=5e-3, max_rel=2.5e-2) if dtype == torch.float16 else dict(rel_rms=2.5e-2, max_rel=0.15)
+    if fp8:     # e4m3 in the five level-0 hybrid blocks (x 2 UNets: the garment UNet stays 16-bit): budget measured, see DESIGN.md
+        bar = dict(rel_rms=4e-2, max_rel=0.3)
     assert st["rel_rms"] < bar["rel_rms"] and st["max_abs"] < bar["max_rel"] * st["ref_std"], st
     keep = (mask == 0).expand(1, 4, -1, -1)       # outside the mask: exactly the original latents after the last step (:494-500)
     assert torch.allclose(out.cpu()[keep], img_lat[keep], atol=1e-5)

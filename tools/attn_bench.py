@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from imagdressing_amd import ops
 
-def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False):
+def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False, fp8=False):
     H = 8
     B = 2 * Bimg
     dpk, dpv = ops.attn_padded_dims(D)
@@ -22,7 +22,16 @@ def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False):
     if qw is not None:
         ops.L.check(ops.L.load().imd_set_tuning(0, qw))
     ops.L.check(ops.L.load().imd_set_tuning(1, xcd))
+    if fp8:
+        e = ops.FP8_EXPS
+        q8 = ops.quantize_fp8_rows(q, e["q"]); k8 = ops.quantize_fp8_rows(k, e["k"], 2.0 ** (e["q"] + e["k"]))
+        kr8 = ops.quantize_fp8_rows(kr, e["k"], 2.0 ** (e["q"] + e["k"]))
+        v8 = ops.quantize_fp8_vt(vt, e["v"]); vr8 = ops.quantize_fp8_vt(vr, e["v"])
+
     def go():
+        if fp8:
+            ops.attention_fp8(q8, k8, v8, out, B=B, H=H, N=N, L1=N, L1P=ops.pad64(N), k2=kr8, v2t=vr8, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B)
+            return
         ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B, k_pad_one=True)
     for _ in range(3): go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -42,13 +51,15 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only-l0", action="store_true")
     ap.add_argument("--variants", default="", help="comma list of knob-0 values to A/B on the level-0 shape")
+    ap.add_argument("--fp8", action="store_true", help="also time imd_attention_fp8 (operands quantised outside the timed region)")
+    ap.add_argument("--N", type=int, default=4096, help="tokens of the level-0 shape (6912 = the 768x576 configuration)")
     ap.add_argument("--zero", action="store_true", help="all-zero Q/K/V: same instruction stream, far fewer toggling bits (clock / power probe)")
     ap.add_argument("--default-only", action="store_true", help="level-0 shape with the library's default knobs only (PMC passes)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     cases = [(40, 4096, 4096, 4, 2, 1), (40, 4096, 4096, 4, 1, 1), (40, 4096, 4096, 4, 2, 0), (40, 4096, 4096, 4, 1, 0)]
     if a.variants:
-        cases = [(40, 4096, 4096, 4, int(v), 1) for v in a.variants.split(",")]
+        cases = [(40, a.N, a.N, 4, int(v), 1) for v in a.variants.split(",")]
     elif a.default_only:
         cases = [(40, 4096, 4096, 4, None, 1)]
     elif not a.only_l0:
@@ -56,4 +67,6 @@ if __name__ == "__main__":
     for rep in range(2):          # interleaved repeats: within-run A/B
         for D, N, M, Bi, qw, xcd in cases:
             print(json.dumps(dict(run(D, N, M, Bi, a.iters, dt, qw, xcd, a.zero), zero=a.zero)), flush=True)
+        if a.fp8:
+            print(json.dumps(dict(run(40, a.N, a.N, 4, a.iters, dt, None, 1, a.zero, fp8=True), fp8=True)), flush=True)
     ops.L.load().imd_set_tuning(0, 1); ops.L.load().imd_set_tuning(1, 1)

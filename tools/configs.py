@@ -87,7 +87,11 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--fp8-attention", action="store_true", help="level-0 attention on the MX-FP8 MFMA (ops.ATTN_FP8)")
     a = ap.parse_args()
+    if a.fp8_attention:
+        from imagdressing_amd import ops
+        ops.ATTN_FP8 = True
     dev = torch.device("cuda", 0)
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     pipe, kw = build(a.config, dev, dt, a.batch or None, a.steps)
@@ -98,6 +102,6 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     dtm = time.perf_counter() - t0
     B = kw["num_images_per_prompt"]
-    print(json.dumps(dict(config=f"BASELINE configs[{a.config - 1}]", dtype=a.dtype, batch=B, steps=a.steps,
+    print(json.dumps(dict(config=f"BASELINE configs[{a.config - 1}]", dtype=a.dtype, fp8_attention=a.fp8_attention, batch=B, steps=a.steps,
                           ms_per_step=round(dtm / a.steps * 1e3, 2), images_per_s_at_50_steps=round(B / (dtm / a.steps * 50), 3),
                           finite=bool(torch.isfinite(out).all()), shape=list(out.shape))))
