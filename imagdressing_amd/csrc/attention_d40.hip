@@ -45,7 +45,9 @@ static_assert((DPV - VROWS) * VSTR <= KT * KSTR, "phantom V^T rows must stay ins
 //   V^T: 128-byte rows back to back; piece c of row d is stored at position c ^ ((d >> 1) & 7)
 // (with either map the 16 rows a ds_read_b128 lane group touches fall on 16 distinct 16-byte bank slots)
 constexpr int KSTR_D = DPK * 2, VSTR_D = KT * 2, VBYTES_D = VROWS * VSTR_D, BUF_D = VBYTES_D + KT * KSTR_D;
-constexpr int LDS_BYTES_D = 2 * BUF_D + PARK;
+constexpr int NRING = 3;                    // LDS-DMA ring: unit u + 2 is in flight while unit u is consumed (an L2 miss served by the
+                                            // Infinity Cache takes about as long as one iteration: one unit of lead was not enough)
+constexpr int LDS_BYTES_D = NRING * BUF_D + PARK + 1024;      // + 1 KB dump for the fourth wave's third (empty) DMA piece
 static_assert((DPV - VROWS) * VSTR_D <= KT * KSTR_D, "phantom V^T rows must stay inside the K rows");
 
 typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u;
@@ -68,6 +70,7 @@ __device__ __forceinline__ void dma16(const v4i_t& rsrc, uint32_t lds_addr, uint
                  : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void dma_wait_keep3() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }   // all but the 3 youngest pieces
 __device__ __forceinline__ v4i_t raw_rsrc(const void* base, uint32_t bytes) {      // stride 0, raw addressing, wave-uniform by construction
     const uint64_t a = (uint64_t)base;
     v4i_t r;
@@ -90,6 +93,7 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
 // ABLATION bits (timing experiments only, results are WRONG): 4: exp2 replaced by a move   8: no barrier in the loop
 //   16: no global loads / LDS stores in the loop   32: no P.V MFMAs   64: no QK^T MFMAs   256: one LDS fragment read per step
 //   512: 100 KB of LDS per workgroup (one workgroup = one wave per SIMD)   2048: no packed-max / overflow test
+//   4096: s_memtime instrumentation (per-phase cycle sums of every wave's loop, added into the first words of `out`)
 template <bool F16, int THR, int VAR>
 __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
     using E = El<F16>;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
     {
         constexpr int PADV = (DMA ? VSTR_D : VSTR) / 16;
         const uint32_t one2 = E::pack2(1.0f, 1.0f);
-        for (int v = tid; v < 2 * PADV; v += 256)
+        for (int v = tid; v < (DMA ? NRING : 2) * PADV; v += 256)
             *reinterpret_cast<uint4*>(smem + (v / PADV) * BUFB + D * (DMA ? VSTR_D : VSTR) + (v % PADV) * 16) = make_uint4(one2, one2, one2, one2);
     }
 
@@ -158,9 +162,10 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) vfd[g] = col * VSTR_D + (((2 * g + hi) ^ sw) * 16);
     }
-    char* park = smem + 2 * BUFB + wave * 5120 + lane * 16;
+    char* park = smem + (DMA ? NRING : 2) * BUFB + wave * 5120 + lane * 16;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+    unsigned long long tm_slots = 0, tm_check = 0, tm_sync = 0, tm_loop = 0, tm_steps = 0;      // VAR & 4096 only
     for (int ph = 0; ph < nph; ++ph) {
         f32x16 o[2][2];
         float m_ref[2] = {0.f, 0.f};
@@ -215,7 +220,9 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int qi = wv + 4 * i;
-            if (qi < 6) {
+            if (qi >= 11) {
+                dsrc[i] = 0; dneg[i] = true;
+            } else if (qi < 6) {
                 const int sl = 64 * qi + lane, r = sl / 6, cs = sl % 6, c = (cs + 6 - 3 * ((r >> 3) & 1)) % 6;
                 dsrc[i] = (32 + r) * (DPK * 2) + c * 16;
                 dneg[i] = r < 32;                                // unit -1: rows 64 u + 32 + r = r - 32
@@ -227,13 +234,13 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         }
         auto dma_unit = [&](int u, int bufi) {     // u >= 1 inside the loop: no range logic at all (rows / columns past the end read 0)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < 3; ++i) {      // EVERY wave issues exactly 3 pieces (the counted vmcnt relies on it)
                 const int qi = wv + 4 * i;
-                if (qi >= 11) continue;
-                const bool isk = qi < 6;
-                const bool bad = isk ? (u < 0 && dneg[i]) : (u <= 0 && (u < 0 || dneg[i]));
+                const bool isk = qi < 6, none = qi >= 11;
+                const bool bad = none || (isk ? (u < 0 && dneg[i]) : (u <= 0 && (u < 0 || dneg[i])));
                 const uint32_t off = bad ? OOB : (uint32_t)(dsrc[i] + u * (isk ? KT * DPK * 2 : KT * 2));
-                const uint32_t dst = smem_base + bufi * BUF_D + (isk ? VBYTES_D + 1024 * qi : 1024 * (qi - 6));
+                const uint32_t dst = none ? smem_base + NRING * BUF_D + PARK
+                                          : smem_base + bufi * BUF_D + (isk ? VBYTES_D + 1024 * qi : 1024 * (qi - 6));
                 dma16(isk ? ds_k : ds_v, dst, off);
             }
         };
@@ -377,12 +384,14 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                     }
                 }
             }
+            if (VAR & 4096) tm_steps += 1;
         };
 
         // ---- prologue: unit -1 (K block 0 in its second half) -> S_a = QK^T(block 0); unit 0 staged behind it ----
         if (DMA) {
-            dma_unit(-1, 1);
+            dma_unit(-1, 2);
             dma_unit(0, 0);
+            dma_unit(1, 1);
             dma_wait();
         } else {
             load_unit(-1);
@@ -391,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         }
         __syncthreads();
         {
-            const char* Ks = smem + BUFB + VBY;
+            const char* Ks = smem + (DMA ? 2 : 1) * BUFB + VBY;           // unit -1
 #pragma unroll
             for (int tk = 0; tk < NKT; ++tk) {
                 const uint4 kf = DMA ? *reinterpret_cast<const uint4*>(Ks + 32 * KSTR_D + kfd[tk])
@@ -408,21 +417,29 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         // (register staging keeps the simpler form: NU full iterations, past-the-end blocks masked to P = 0 on the exact path)
         const int NUF = DMA ? (J >> 1) : NU;
         auto iteration_sync = [&]() {
-            if (DMA) dma_wait();                                    // this wave's pieces of the next unit have landed ...
+            if (DMA) dma_wait_keep3();                              // this wave's pieces of unit u + 1 have landed (u + 2 stays in flight) ...
             if (!(VAR & 8)) __syncthreads();                        // ... and so have everybody else's
         };
+        int ring = 0;                                               // u % NRING
+        unsigned long long t_loop0 = 0;
+        if (VAR & 4096) t_loop0 = __builtin_amdgcn_s_memtime();
         for (int u = 0; u < NUF; ++u) {
             if (DMA) {
-                if (!(VAR & 16)) dma_unit(u + 1, (u + 1) & 1);      // buffer (u+1)&1 was last read in iteration u-1
+                if (!(VAR & 16)) dma_unit(u + 2, ring == 0 ? 2 : ring - 1);      // buffer (u+2) % 3 was last read in iteration u-1
             } else if (!(VAR & 16)) load_unit(u + 1);
-            const char* Vs = smem + (u & 1) * BUFB;
+            const char* Vs = smem + (DMA ? ring : (u & 1)) * BUFB;
+            ring = ring == NRING - 1 ? 0 : ring + 1;
             step(Vs, std::false_type{}, 2 * u, sa, sb, pa, pb);
             step(Vs, std::true_type{}, 2 * u + 1, sb, sa, pb, pa);
             if (!DMA && !(VAR & 16)) store_unit((u + 1) & 1);
+            unsigned long long t_s = 0;
+            if (VAR & 4096) t_s = __builtin_amdgcn_s_memtime();
             iteration_sync();
+            if (VAR & 4096) tm_sync += __builtin_amdgcn_s_memtime() - t_s;
         }
+        if (VAR & 4096) tm_loop += __builtin_amdgcn_s_memtime() - t_loop0;
         if (DMA) {
-            const char* Vs = smem + (NUF & 1) * BUFB;
+            const char* Vs = smem + ring * BUFB;                     // unit NUF
             auto drain = [&](int g0, const uint4 (&pp)[2][2]) {      // O += V^T P^T of the last block; nothing left to score
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
@@ -440,7 +457,8 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
             } else {
                 drain(0, pb);
             }
-            __syncthreads();          // the next phase restages both buffers
+            dma_wait();               // pieces of units past the end are still landing: the next phase restages every buffer
+            __syncthreads();
         }
 
         // ---- end of phase: normalise; phase 0 of a two-phase row is parked in LDS rounded to the element type (the
@@ -471,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                     *reinterpret_cast<uint2*>(park + (qb * 5 + jj) / 2 * 1024 + ((qb * 5 + jj) & 1) * 8) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
             } else {
                 const int q = q0 + qb * 32 + col;
-                if (q < p.N) {
+                if (q < p.N && !(VAR & 4096)) {
                     bf16_t* orow = p.out + ((size_t)b * p.N + q) * p.out_ld + h * D;
 #pragma unroll
                     for (int jj = 0; jj < 5; ++jj)
@@ -479,6 +497,11 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                 }
             }
         }
+    }
+    if ((VAR & 4096) && lane == 0) {       // (the kernel's real output is garbage in this variant: the counters overwrite its head)
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out);
+        atomicAdd(dbg + 0, tm_loop); atomicAdd(dbg + 1, tm_slots); atomicAdd(dbg + 2, tm_check); atomicAdd(dbg + 3, tm_sync);
+        atomicAdd(dbg + 4, tm_steps); atomicAdd(dbg + 5, 1ull);
     }
 }
 
@@ -521,6 +544,16 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
         case 18: return launch_attn40<false, 8, 1 | 4 | 16 | 256>(p, s);   // MFMAs + pack only
         case 19: return launch_attn40<false, 8, 1 | 32 | 64 | 16>(p, s);   // 2 MFMAs per step, everything else
         case 20: return launch_attn40<false, 8, 1 | 128 | 2048>(p, s);     // LDS-DMA variant without the packed-max / overflow test
+        case 21: return launch_attn40<false, 8, 1 | 128 | 4096>(p, s);     // cycle counters (tools/attn_bench.py --cycles)
+        case 22: return launch_attn40<false, 8, 1 | 128 | 4096 | 512>(p, s);   // ... with one workgroup per CU
+        // one workgroup per CU (a lone wave per SIMD): what is that wave's step made of
+        case 23: return launch_attn40<false, 8, 1 | 128 | 512>(p, s);
+        case 24: return launch_attn40<false, 8, 1 | 128 | 512 | 4>(p, s);              // no exp2
+        case 25: return launch_attn40<false, 8, 1 | 128 | 512 | 16>(p, s);             // no staging
+        case 26: return launch_attn40<false, 8, 1 | 128 | 512 | 32>(p, s);             // no P.V MFMAs
+        case 27: return launch_attn40<false, 8, 1 | 128 | 512 | 32 | 64>(p, s);        // 2 MFMAs per step
+        case 28: return launch_attn40<false, 8, 1 | 128 | 512 | 4 | 16 | 2048>(p, s);  // MFMAs, packs and fragment reads only
+        case 29: return launch_attn40<false, 8, 1 | 128 | 512 | 8>(p, s);              // no barrier
         default: return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
     }
 }

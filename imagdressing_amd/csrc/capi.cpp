@@ -86,7 +86,7 @@ int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long coun
 
 int imd_set_tuning(int knob, int value) {
     switch (knob) {
-        case 0: IMD_REQUIRE(value >= 1 && value <= 20, "set_tuning: attention variant for head dim 40 must be 1..20 (10..20: timing ablations, wrong results)"); g_attn_qw40 = value; return 0;
+        case 0: IMD_REQUIRE(value >= 1 && value <= 29, "set_tuning: attention variant for head dim 40 must be 1..29 (10..29: timing ablations, wrong results)"); g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
         case 2: g_gemm_flags = value & 31; return 0;
         default: return imd_set_error("set_tuning: unknown knob %d", knob);

@@ -43,7 +43,14 @@ def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False, fp8=False):
     fl = Bimg * (4.0 * N * N * C + 4.0 * N * M * C) + Bimg * 4.0 * N * N * C
     # algorithmic HBM bytes: Q,K read + V^T read (D rows) per row, garment K/V once per (cond row, head) from L2/HBM, O written
     alg_bytes = 2 * (B * H * N * dpk * 2) + B * H * D * N * 2 + H * (M * dpk + D * M) * 2 + B * N * C * 2
-    return dict(D=D, N=N, M=M, Bimg=Bimg, qw=qw, xcd=xcd, us=round(us, 1), tflops=round(fl / us / 1e6, 1), flops=fl, alg_bytes=alg_bytes)
+    extra = {}
+    if qw in (21, 22):
+        out.zero_(); go(); torch.cuda.synchronize()
+        c = out.view(torch.int64).flatten()[:6].tolist()
+        waves, steps = max(c[5], 1), max(c[4], 1)
+        extra = dict(cycles_per_step=dict(loop_total=round(c[0] / steps, 1), slots=round(c[1] / steps, 1), check=round(c[2] / steps, 1),
+                                          sync_per_step=round(c[3] / steps, 1)), steps_per_wave=round(steps / waves, 1), waves=waves)
+    return dict(extra, D=D, N=N, M=M, Bimg=Bimg, qw=qw, xcd=xcd, us=round(us, 1), tflops=round(fl / us / 1e6, 1), flops=fl, alg_bytes=alg_bytes)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -51,6 +58,7 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only-l0", action="store_true")
     ap.add_argument("--variants", default="", help="comma list of knob-0 values to A/B on the level-0 shape")
+    ap.add_argument("--cycles", action="store_true", help="variants 21 / 22: print the in-kernel s_memtime counters (per wave and 32-key step)")
     ap.add_argument("--fp8", action="store_true", help="also time imd_attention_fp8 (operands quantised outside the timed region)")
     ap.add_argument("--N", type=int, default=4096, help="tokens of the level-0 shape (6912 = the 768x576 configuration)")
     ap.add_argument("--zero", action="store_true", help="all-zero Q/K/V: same instruction stream, far fewer toggling bits (clock / power probe)")
