@@ -88,6 +88,8 @@ SYMBOLS = {
     "imd_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p]),
     "imd_groupnorm_coeffs": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "imd_conv_patch_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
+    "imd_row_linear": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int, C.c_float, C.c_void_p]),
+    "imd_row_linear_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_groupnorm_workspace_floats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "imd_layernorm": (C.c_int, [C.POINTER(LayerNormParams), C.c_void_p]),
     "imd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -120,8 +122,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if lib.imd_abi_version() != 2:
-            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 2")
+        if lib.imd_abi_version() != 3:
+            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 3")
         _lib = lib
     return _lib
 

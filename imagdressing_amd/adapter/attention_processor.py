@@ -138,6 +138,23 @@ def _layer_weights(attn, which: str, dtype, device) -> torch.Tensor:
     return ent[2]
 
 
+def _ln_folded_q(attn, gamma: torch.Tensor, beta: torch.Tensor, dtype, device):
+    """(W_q diag(gamma), W_q beta) for the fused ``LayerNorm -> to_q`` launch (ops.conv_gemm ``ln_eps``), cached on the module
+    against the identity / version of to_q.weight and the two norm parameters."""
+    srcs = (attn.to_q.weight, gamma, beta)
+    cache = attn.__dict__.setdefault("_imd_wcache", {})
+    key = (_version_key(*srcs), dtype, str(device))
+    ent = cache.get("q_ln")
+    if ent is None or ent[0] != key or not all(a is b for a, b in zip(ent[1], srcs)):
+        w = attn.to_q.weight.detach().to(device=device, dtype=dtype)
+        ent = cache["q_ln"] = (key, srcs, ops.fold_layernorm_affine(w, None, gamma.to(device), beta.to(device)))
+    return ent[2]
+
+
+# channel count the row-resident ``LayerNorm -> linear`` kernel exists for (csrc/row_linear.hip: the 64x64 level of SD1.5)
+FUSED_LN_CHANNELS = 320
+
+
 def _as_tokens(hidden_states: torch.Tensor, dtype):
     """Accept [B, N, C] (transformer blocks) or [B, C, H, W] (attention_processor.py:548-552); cast to the
     16-bit element type of the layer's packed weights (bf16 or fp16)."""
@@ -197,8 +214,10 @@ def _fp8_kv(kv, cache: bool):
 
 def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, self_attn: bool,
                      kv1=None, kv1_bdiv: int = 1, kv2=None, kv2_bdiv: int = 1, scale2: Optional[torch.Tensor] = None,
-                     wo: torch.Tensor, bo: Optional[torch.Tensor], residual: Optional[torch.Tensor]) -> torch.Tensor:
-    """x [B, N, C] bf16 -> out-projected attention output [B, N, C] (+ residual)."""
+                     wo: torch.Tensor, bo: Optional[torch.Tensor], residual: Optional[torch.Tensor],
+                     q_ln: Optional[tuple] = None) -> torch.Tensor:
+    """x [B, N, C] bf16 -> out-projected attention output [B, N, C] (+ residual).  ``q_ln`` = (W_q', b_q', eps): ``x`` is the
+    block's UN-normalised hidden state and LayerNorm runs inside the Q projection (cross-attention, C = 320 only)."""
     B, N, Cc = x.shape
     D = Cc // heads
     dpk, dpv = ops.attn_padded_dims(D)
@@ -213,6 +232,9 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
         ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=3 * Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1,
                       heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale), (k, 0, dpk, N, 1.0), (vt, 1, dpv, LP, 1.0)]))
         kv1, kv1_bdiv = (k, vt, N, LP), 1
+    elif q_ln is not None:
+        ops.conv_gemm(x2, q_ln[0], M=B * N, N=Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1, bias=q_ln[1], ln_eps=q_ln[2],
+                      heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale)]))
     else:
         ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1,
                       heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale)]))
@@ -262,6 +284,10 @@ class _FusedBase:
 class AttnProcessor2_0(_FusedBase):
     """Plain attention (diffusers' default processor; what a ControlNet / un-patched UNet runs)."""
 
+    # engine-side extension (like fused_residual): for cross-attention on FUSED_LN_CHANNELS channels the engine may hand in the
+    # block's un-normalised hidden state plus ``imd_layernorm=(gamma, beta, eps)``; LayerNorm then runs inside the Q projection
+    fused_layernorm = True
+
     def __init__(self, cache_entries: int = 256):
         # ONE instance may serve every attention layer of a model (``set_attn_processor(proc)``, as diffusers
         # does): cached K/V are keyed by the conditioning tensor AND the layer's own projection weights, hence the
@@ -270,11 +296,18 @@ class AttnProcessor2_0(_FusedBase):
         self._text = _TensorCache(capacity=cache_entries)
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
-                 imd_residual=None, **kwargs):
+                 imd_residual=None, imd_layernorm=None, **kwargs):
         dt = _compute_dtype(attn, hidden_states, attention_mask)
         x, shape4 = _as_tokens(hidden_states, dt)
         dev = x.device
         wo, bo = _layer_weights(attn, "o", dt, dev), _layer_weights(attn, "bo", dt, dev)
+        q_ln = None
+        if imd_layernorm is not None:
+            g, be, eps = imd_layernorm
+            if encoder_hidden_states is not None and x.shape[-1] == FUSED_LN_CHANNELS:
+                q_ln = _ln_folded_q(attn, g, be, dt, dev) + (eps,)
+            else:
+                x = ops.layer_norm(x, g, be, eps)
         if encoder_hidden_states is None:
             out = _fused_attention(x, attn.heads, wq_or_qkv=_layer_weights(attn, "qkv", dt, dev), self_attn=True, wo=wo, bo=bo,
                                    residual=imd_residual)
@@ -286,12 +319,13 @@ class AttnProcessor2_0(_FusedBase):
                 kv = self._text.put(srcs, _project_kv(e, _layer_weights(attn, "kv", dt, dev), attn.heads), extra=(dt,))
             out = _fused_attention(x, attn.heads, wq_or_qkv=_layer_weights(attn, "q", dt, dev), self_attn=False, kv1=kv,
                                    kv1_bdiv=self._ehs_bdiv(x.shape[0], encoder_hidden_states), wo=wo, bo=bo,
-                                   residual=imd_residual)
+                                   residual=imd_residual, q_ln=q_ln)
         return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
 
 
 class CacheAttnProcessor2_0(AttnProcessor2_0):
     """Garment-UNet processor: remembers its *input* (attention_processor.py:34), then plain attention."""
+    fused_layernorm = False      # the cached tensor must be the normalised hidden state the reference caches
 
     def __init__(self):
         super().__init__()
@@ -455,9 +489,12 @@ class CAttnProcessor2_0(nn.Module, _FusedBase):
         self.cross_attention_dim = cross_attention_dim
         self._plain = AttnProcessor2_0(cache_entries=4)
 
+    fused_layernorm = True
+
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
-                 cond_hidden_states=None, sa_hidden_states=None, imd_residual=None, **kwargs):
-        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
+                 cond_hidden_states=None, sa_hidden_states=None, imd_residual=None, imd_layernorm=None, **kwargs):
+        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual,
+                           imd_layernorm=imd_layernorm)
 
 
 class _IPBase(nn.Module, _FusedBase, _LoraFold):

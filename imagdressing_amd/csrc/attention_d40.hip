@@ -24,6 +24,7 @@
 //   * the phase-0 (self) result of a two-phase row is parked in LDS (16-bit, the rounding the reference's first SDPA
 //     output has), not in the output buffer: no HBM round trip, no store -> load dependency at the phase boundary.
 #include <type_traits>
+#include "lds_dma.h"
 
 #include "common.h"
 #include "imd_kernels.h"
@@ -56,30 +57,6 @@ __device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, ui
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 constexpr uint32_t OOB = 0xffffffffu;
-
-// One LDS-DMA piece: 64 lanes x 16 bytes from `rsrc` at per-lane byte offset `voff` (out of range reads 0) to LDS bytes
-// [lds_addr, lds_addr + 1024).  Inline asm on purpose: through the builtin hipcc assumes the DMA may alias every later
-// ds_read of the kernel's one LDS array and drains it (s_waitcnt vmcnt(0)) in front of the first fragment read -- the
-// whole point is to keep it in flight for an iteration.  Completion is waited for by hand (dma_wait) before the barrier
-// that publishes the unit.  M0 (the DMA's LDS base) is saved and restored inside the statement; the leading s_nop covers a
-// descriptor / offset register written by a VALU just before (hipcc does not see hazards inside an asm string).
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void dma16(const v4i_t& rsrc, uint32_t lds_addr, uint32_t voff) {
-    uint32_t keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void dma_wait_keep3() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }   // all but the 3 youngest pieces
-__device__ __forceinline__ v4i_t raw_rsrc(const void* base, uint32_t bytes) {      // stride 0, raw addressing, wave-uniform by construction
-    const uint64_t a = (uint64_t)base;
-    v4i_t r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(uint32_t)a);
-    r[1] = __builtin_amdgcn_readfirstlane((int)((uint32_t)(a >> 32) & 0xffffu));
-    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
-    r[3] = 0x00020000;
-    return r;
-}
 
 // packed 3-input maximum: on non-negative 16-bit float patterns (fp16 OR bf16) it is the maximum of the patterns as
 // integers, with inf / NaN patterns propagating

@@ -88,7 +88,7 @@ int imd_set_tuning(int knob, int value) {
     switch (knob) {
         case 0: IMD_REQUIRE(value >= 1 && value <= 29, "set_tuning: attention variant for head dim 40 must be 1..29 (10..29: timing ablations, wrong results)"); g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
-        case 2: g_gemm_flags = value & 31; return 0;
+        case 2: g_gemm_flags = value & 511; return 0;   // (bit 8: row_linear staged epilogue, A/B only)
         default: return imd_set_error("set_tuning: unknown knob %d", knob);
     }
 }
@@ -111,6 +111,22 @@ int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* co
 }
 
 int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (p && imd_conv_patch_supported(*p)) ? 1 : 0; }
+
+int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (p && imd_row_linear_supported(*p)) ? 1 : 0; }
+
+int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* stream) {
+    IMD_REQUIRE(p != nullptr, "row_linear: null params");
+    IMD_REQUIRE(p->x && p->w, "row_linear: null input/weight pointer");
+    IMD_REQUIRE(p->mode == IMD_OUT_HEADS || p->out != nullptr, "row_linear: null output pointer");
+    IMD_REQUIRE(p->Hout > 0 && p->Wout > 0 && p->M > 0 && p->M % (p->Hout * p->Wout) == 0, "row_linear: bad geometry");
+    if (p->mode == IMD_OUT_HEADS) {
+        IMD_REQUIRE(p->hC > 0 && p->hH > 0 && p->hD > 0 && p->hC == p->hH * p->hD && p->N % p->hC == 0 && p->N / p->hC <= 3 && p->hD % 8 == 0,
+                    "row_linear: bad head split C=%d H=%d D=%d", p->hC, p->hH, p->hD);
+        IMD_REQUIRE(!p->out_f32, "row_linear: head-split output excludes fp32 output");
+    }
+    IMD_REQUIRE(!ln || ln_eps > 0.f, "row_linear: LayerNorm needs eps > 0");
+    return imd_launch_row_linear(*p, ln, ln_eps, (hipStream_t)stream);
+}
 
 int imd_layernorm(const imd_layernorm_params* p, void* stream) {
     IMD_REQUIRE(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");

@@ -438,6 +438,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
             return imd_check_launch("conv_patch split-K finish");
         }
+        case 12: return imd_launch_row_linear(p, 0, 0.f, s);      // row-resident kernel (row_linear.hip): K = 320, N <= 320
         default: return imd_set_error("conv_gemm: unknown tile config %d", cfg);
     }
 }

@@ -14,6 +14,11 @@ __device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t& rs, ui
 }
 // same, served from L2 without allocating in the CU's 32 KiB vector L1 (sc1): used for the weight stream so that
 // the L1 keeps the activation lines that neighbouring 3x3 taps re-read
+__device__ __forceinline__ uint2 buf_load8(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
+    typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
+    const v2u v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)byte_off, 0, 0);
+    return make_uint2(v[0], v[1]);
+}
 __device__ __forceinline__ uint4 buf_load16_nl1(const __amdgpu_buffer_rsrc_t& rs, uint32_t byte_off) {
     const v4u v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16);
     return make_uint4(v[0], v[1], v[2], v[3]);

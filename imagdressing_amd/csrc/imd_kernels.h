@@ -26,6 +26,8 @@ int imd_conv_gemm_choose_split(int M, int N, int K, int cfg);
 int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
 bool imd_conv_patch_supported(const ConvGemmParams& p);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
+bool imd_row_linear_supported(const ConvGemmParams& p);                                    // row_linear.hip
+int imd_launch_row_linear(const ConvGemmParams& p, int ln, float ln_eps, hipStream_t s);
 int imd_launch_attention(const AttnParams& p, hipStream_t s);
 int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s);
 int imd_launch_attention_fp8(const AttnParams& p, int eq, int ek, int ev, hipStream_t s);                       // attention_d40_fp8.hip

@@ -1,0 +1,286 @@
+// Row-resident linear layer for the level-0 token matrix (K = 320; N = 64 .. 320 in steps of 64):
+//
+//   out[m, :] = epilogue( LN?(x[m, :]) . W^T )          m = token, M ~ 32768, K = 320
+//
+// The tiled implicit-GEMM kernel (conv_gemm.hip) walks K in 32/64-element steps: on this shape every step is a round
+// trip to memory for 64-byte row pieces with two tiles of lead, a barrier per step, and the kernel ends up at ~0.10 of the
+// MFMA peak although it is not even HBM-bound (profiles/r2h_*).  Here the roles are turned around:
+//   * a workgroup (8 waves) owns 128 complete token rows.  Each wave requests ITS 32 rows x 640 bytes -- one contiguous
+//     20 KB span -- with 20 back-to-back 16-byte loads per lane, straight into the MFMA B-operand layout (lane = token,
+//     8 consecutive k per 16-k step), and keeps them in 80 VGPRs for the whole kernel: all activation bytes of the launch
+//     are in flight at once, there is no K loop on the activation side and no barrier coupled to memory latency.
+//   * the weight matrix streams through LDS in chunks of 64 output channels x 320 k (40 KB) by LDS-DMA
+//     (buffer_load ... lds, 3-slot ring, counted vmcnt, one barrier per chunk), shared by the 8 waves; rows are stored
+//     unpadded with the 16-byte pieces of row r XOR-ed by (r >> 1) & 7 on the SOURCE side, which makes the ds_read_b128
+//     fragment reads conflict-free.
+//   * all N <= 320 output channels of a wave's 32 tokens stay in accumulators (80 VGPRs) until the end, so no store is in
+//     flight while DMA pieces are being counted; the fp32 tile then crosses LDS once (the ring is dead by then) and leaves
+//     through the same fused 8-channel epilogue as the tiled kernel (bias / residual / head-split Q layout ...).
+//   * optional LayerNorm prologue (LN): mean / variance of each token row are taken from the registers (two-pass, fp32;
+//     the two lanes that share a row exchange one partial each) and the rows are normalised in place; the affine part is
+//     folded into the weights by the caller (W' = W diag(gamma), b' = b + W beta), so `layernorm -> linear` is ONE launch
+//     and the normalised tensor never exists in memory.
+// Reference arithmetic: diffusers==0.24.0 BasicTransformerBlock / Transformer2DModel (un-vendored; call sites
+// /root/reference/dressing_sd/pipelines/IMAGDressing_v1_pipeline.py:499,511): proj_in, attn.to_out[0] (+ residual),
+// norm2 -> attn2.to_q, proj_out (+ residual), and adapter/attention_processor.py:568 (to_q), :617 (to_out) on the 64x64 level.
+#include "gemm_common.h"
+#include "lds_dma.h"
+
+namespace {
+
+constexpr int RL_K = 320;
+constexpr int RL_STEPS = RL_K / 16;              // 20 MFMA k-steps
+constexpr int RL_ROWB = RL_K * 2;                // bytes per weight row
+constexpr int RL_CH = 64;                        // output channels per weight chunk
+constexpr int RL_CHUNK = RL_CH * RL_ROWB;        // 40960 bytes
+constexpr int RL_PIECES = RL_CHUNK / (8 * 1024); // DMA pieces per wave per chunk: 5
+constexpr int RL_RING = 3;
+constexpr int RL_BM = 128;
+constexpr int RL_CLD = 320 + 4;                  // fp32 epilogue tile leading dimension
+constexpr int RL_LDS = RL_RING * RL_CHUNK;       // 122880 >= 64 * RL_CLD * 4 = 82944
+constexpr int RL_LDS_TOTAL = RL_LDS + 320 * 4;   // + the bias vector of the direct epilogue
+static_assert(RL_PIECES == 5, "dma_wait_keep5 assumes five pieces per chunk");
+
+template <bool F16, int NC, bool LN, bool DIRECT>
+__global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams p, const float ln_eps) {
+    using E = El<F16>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, col = lane & 31;
+    const int rb = wave & 3;            // 32-token block of the workgroup's 128 rows
+    const int chh = wave >> 2;          // which 32-channel half of every 64-channel weight chunk
+    const int m0 = blockIdx.x * RL_BM;
+
+    // ---- activations: this wave's 32 rows, all of K, straight into B-operand fragments ----
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const int m = m0 + rb * 32 + col;
+    const uint32_t xoff = (uint32_t)m * (uint32_t)(p.x_pix_stride * 2) + hi * 16;
+    uint4 xf[RL_STEPS];
+#pragma unroll
+    for (int s = 0; s < RL_STEPS; ++s) xf[s] = buf_load16(rs_x, m < p.M ? xoff + s * 32 : OOB);
+
+    // DIRECT epilogue (row-major 16-bit output or head-split Q; bias / scale / residual only): every chunk's 32 x 32 block
+    // leaves straight from the accumulators while the NEXT chunk is being multiplied, so the output stream overlaps the
+    // MFMA phase instead of following it (all 256 workgroups run in lock-step: an epilogue at the end is fully exposed --
+    // measured 9 us of the 21; HBM absorbs writes at only ~2.3 TB/s, so the 21 MB of output are the longest phase and
+    // everything else should hide under them).  The residual of chunk c is requested while chunk c is multiplied and
+    // consumed one chunk later, so its 21 MB ride under the output stream as well; the bias sits in LDS behind the ring.
+    uint2 rres[2][4];
+    const bool has_res = DIRECT && !LN && p.res != nullptr;      // (LayerNorm + residual: staged epilogue)
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, 0x80000000u, 0x00020000);
+    const uint32_t roff = (uint32_t)m * (uint32_t)(p.res_ld * 2) + (uint32_t)((wave >> 2) * 64 + hi * 8);
+    auto load_res = [&](int c) {        // residual of chunk c in accumulator layout (lane = token, 4 consecutive channels per 8-byte load)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[c & 1][j] = buf_load8(rs_r, m < p.M ? roff + (uint32_t)(c * 128 + j * 16) : OOB);
+    };
+    float bias_v = 0.f;              // requested behind the activation rows; parked in LDS once they have arrived (below)
+    if (DIRECT && tid < NC * RL_CH && p.bias) bias_v = p.bias[tid];
+
+    // ---- weight stream: source offsets of this lane's five pieces of a chunk (piece q of the chunk lands at LDS slot q) ----
+    const v4i_t ds_w = raw_rsrc(p.w, p.w_bytes);
+    uint32_t woff[RL_PIECES];
+#pragma unroll
+    for (int j = 0; j < RL_PIECES; ++j) {
+        const int q = (j * 8 + wave) * 64 + lane;
+        const int row = q / 40, pos = q - row * 40;
+        woff[j] = (uint32_t)(row * RL_ROWB + ((pos ^ ((row >> 1) & 7)) << 4));
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;      // LDS aperture offset of the dynamic array
+    auto stage = [&](int c) {
+        const uint32_t base = lds0 + (uint32_t)((c % RL_RING) * RL_CHUNK) + (uint32_t)wave * 1024u;
+#pragma unroll
+        for (int j = 0; j < RL_PIECES; ++j) dma16(ds_w, base + j * 8192u, woff[j] + (uint32_t)c * RL_CHUNK);
+    };
+    stage(0);
+    if (NC > 1) stage(1);
+    // hipcc counts only its own (activation) loads: pin their wait HERE, where it also covers chunks 0 and 1 that were
+    // requested with them, instead of in front of the last MFMA of chunk 0 where it would drain chunk 2 as well
+#pragma unroll
+    for (int s = 0; s < RL_STEPS; ++s) asm volatile("" : "+v"(xf[s].x), "+v"(xf[s].y), "+v"(xf[s].z), "+v"(xf[s].w));
+    if (DIRECT && tid < NC * RL_CH) reinterpret_cast<float*>(smem + RL_LDS)[tid] = bias_v;     // published by the first barrier of the chunk loop
+
+    if constexpr (LN) {      // rows normalised in place (affine folded into W / bias by the caller)
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < RL_STEPS; ++s) {
+            float f[8];
+            unpack8<F16>(xf[s], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += f[e];
+        }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / RL_K);
+        float sq = 0.f;
+        // (opaque touch: keeps hipcc from holding all 160 unpacked values of the row alive across the passes)
+#pragma unroll
+        for (int s = 0; s < RL_STEPS; ++s) asm volatile("" : "+v"(xf[s].x), "+v"(xf[s].y), "+v"(xf[s].z), "+v"(xf[s].w));
+#pragma unroll
+        for (int s = 0; s < RL_STEPS; ++s) {
+            float f[8];
+            unpack8<F16>(xf[s], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; sq = fmaf(d, d, sq); }
+        }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = rsqrtf(sq * (1.0f / RL_K) + ln_eps);
+        const float shift = -mean * rstd;
+#pragma unroll
+        for (int s = 0; s < RL_STEPS; ++s) asm volatile("" : "+v"(xf[s].x), "+v"(xf[s].y), "+v"(xf[s].z), "+v"(xf[s].w));
+#pragma unroll
+        for (int s = 0; s < RL_STEPS; ++s) {
+            float f[8];
+            unpack8<F16>(xf[s], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], rstd, shift);
+            xf[s] = pack8<F16>(f);
+        }
+    }
+
+    f32x16 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    // direct epilogue of chunk c: channels c*64 + chh*32 + 8j + 4hi .. +3 of token m
+    const int HWo = p.Hout * p.Wout;
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+        p.mode == OUT_HEADS ? (void*)p.hd[0].ptr : p.out, 0, 0x80000000u, 0x00020000);
+    uint32_t obase = OOB;            // byte offset of (token m, channel 0) in the row-major case / of (bi, head 0, tok, 0) for head-split Q
+    if (DIRECT && m < p.M) {
+        if (p.mode == OUT_HEADS) { const int bi = m / HWo, tok = m - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
+        else obase = (uint32_t)m * (uint32_t)(p.out_ld * 2);
+    }
+    auto emit = [&](int c) {
+        const float* bias_s = reinterpret_cast<const float*>(smem + RL_LDS);
+        const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = c * 64 + chh * 32 + 8 * j + 4 * hi;
+            const float4 bb = *reinterpret_cast<const float4*>(bias_s + n);
+            float v0 = (acc[c][4 * j] + bb.x) * osc, v1 = (acc[c][4 * j + 1] + bb.y) * osc;
+            float v2 = (acc[c][4 * j + 2] + bb.z) * osc, v3 = (acc[c][4 * j + 3] + bb.w) * osc;
+            if (has_res) {
+                v0 += E::lo(rres[c & 1][j].x); v1 += E::hi(rres[c & 1][j].x);
+                v2 += E::lo(rres[c & 1][j].y); v3 += E::hi(rres[c & 1][j].y);
+            }
+            uint32_t off;
+            if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; off = (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
+            else off = (uint32_t)(n * 2);
+            typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
+            const v2u pk = {E::pack2(v0, v1), E::pack2(v2, v3)};
+            __builtin_amdgcn_raw_buffer_store_b64(pk, rs_o, (int)(obase == OOB ? OOB : obase + off), 0, 0);
+        }
+    };
+
+    const int wrow = chh * 32 + col;                                     // weight row inside a chunk
+    const uint32_t a16 = (uint32_t)((hi ^ ((wrow >> 1) & 7)) << 4);      // piece 2s + hi of row wrow sits at ((2s) ^ (hi ^ f)) * 16
+    const char* wlane = smem + wrow * RL_ROWB;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        // this wave's pieces of chunk c have landed (chunk c + 1 may still fly).  With the direct epilogue stores are in
+        // flight too, and loads and stores do not retire in order with each other: no counted wait, drain everything (the
+        // youngest operations are one whole chunk old by now).
+        if (DIRECT || c + 1 >= NC) dma_wait(); else dma_wait_keep5();
+        __syncthreads();                                          // ... and everybody else's; all waves are done with chunk c - 1
+        // order matters: hipcc drains the memory counter in front of emit()'s use of the residual registers (loads and stores
+        // pending together) -- at this point nothing is in flight, after stage() the fresh DMA pieces would be
+        if (DIRECT && c > 0) emit(c - 1);
+        if (c + 2 < NC) stage(c + 2);                             // into the slot chunk c - 1 just vacated
+        if (has_res) load_res(c);
+        const char* Ws = wlane + (c % RL_RING) * RL_CHUNK;
+#pragma unroll
+        for (int s = 0; s < RL_STEPS; ++s) {
+            const uint4 wf = *reinterpret_cast<const uint4*>(Ws + ((uint32_t)(s * 32) ^ a16));
+            acc[c] = E::mfma(wf, xf[s], acc[c]);
+        }
+    }
+
+    if constexpr (DIRECT) { emit(NC - 1); return; }
+    // ---- staged epilogue (activations, fp32 output, V^T head layouts ...): 64 rows at a time through LDS (fp32), then 8
+    // consecutive channels of a row per thread through the shared epilogue8 ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CPR = NC * 8;                  // 8-channel chunks per row
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        if ((rb >> 1) == half) {
+            float* dst0 = Cs + ((rb & 1) * 32 + col) * RL_CLD + chh * 32 + 4 * hi;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(dst0 + c * 64 + 8 * j) = make_float4(acc[c][4 * j], acc[c][4 * j + 1], acc[c][4 * j + 2], acc[c][4 * j + 3]);
+        }
+        __syncthreads();
+        for (int t = tid; t < 64 * CPR; t += 512) {
+            const int row = t / CPR, cc = (t - row * CPR) * 8;
+            const int mm = m0 + half * 64 + row;
+            if (mm >= p.M) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * RL_CLD + cc);
+            const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * RL_CLD + cc + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            epilogue8<F16>(p, v, mm, cc, 8, HWo);
+        }
+    }
+}
+
+template <bool F16, int NC, bool LN, bool DIRECT>
+int launch_rl_d(const ConvGemmParams& p, float eps, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = row_linear_kernel<F16, NC, LN, DIRECT>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS_TOTAL);
+        if (e != hipSuccess) return imd_set_error("row_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + RL_BM - 1) / RL_BM)), dim3(512), RL_LDS_TOTAL, s, p, eps);
+    return imd_check_launch("row_linear");
+}
+
+template <bool F16, int NC, bool LN>
+int launch_rl(const ConvGemmParams& p, float eps, hipStream_t s) {
+    const bool direct = p.act == ACT_NONE && !p.out_f32 && p.rowvec == nullptr && (g_gemm_flags & 256) == 0 &&
+                        (p.mode == OUT_ROWMAJOR || (p.hd[0].kind == 0 && p.hd[0].ptr != nullptr && p.N == p.hC));
+    const size_t ob = p.mode == OUT_HEADS ? (size_t)(p.M / (p.Hout * p.Wout)) * p.hH * p.hd[0].L * p.hd[0].DP * 2 : ((size_t)(p.M - 1) * p.out_ld + p.N) * 2;
+    const size_t rb = p.res ? ((size_t)(p.M - 1) * p.res_ld + p.N) * 2 : 0;
+    if (direct && !(LN && p.res) && ob < 0x80000000ull && rb < 0x80000000ull) return launch_rl_d<F16, NC, LN, true>(p, eps, s);
+    return launch_rl_d<F16, NC, LN, false>(p, eps, s);
+}
+
+template <bool F16, bool LN>
+int launch_rl_n(const ConvGemmParams& p, float eps, hipStream_t s) {
+    switch (p.N / RL_CH) {
+        case 1: return launch_rl<F16, 1, LN>(p, eps, s);
+        case 2: return launch_rl<F16, 2, LN>(p, eps, s);
+        case 3: return launch_rl<F16, 3, LN>(p, eps, s);
+        case 4: return launch_rl<F16, 4, LN>(p, eps, s);
+        default: return launch_rl<F16, 5, LN>(p, eps, s);
+    }
+}
+
+}  // namespace
+
+bool imd_row_linear_supported(const ConvGemmParams& p) {
+    return p.taps == 1 && p.K == RL_K && p.Cin == RL_K && p.stride == 1 && !p.ups && p.Hin == p.Hout && p.Win == p.Wout &&
+           p.N >= RL_CH && p.N <= 320 && (p.N % RL_CH) == 0 && p.split_k <= 1 && p.act != ACT_GEGLU && p.gn_a == nullptr && (p.x_pix_stride % 8) == 0;
+}
+
+// ln != 0: LayerNorm (no affine) over the K = 320 channels of every row is applied to x on the fly
+int imd_launch_row_linear(const ConvGemmParams& p_in, int ln, float ln_eps, hipStream_t s) {
+    ConvGemmParams p = p_in;
+    if (!imd_row_linear_supported(p))
+        return imd_set_error("row_linear: needs a plain linear layer with K = 320 and N = 64..320 in steps of 64 (got N=%d K=%d taps=%d split=%d)", p.N, p.K, p.taps, p.split_k);
+    if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("row_linear: unknown dtype %d", p.dtype);
+    const size_t xb = ((size_t)(p.M - 1) * p.x_pix_stride + p.K) * 2, wb = (size_t)p.N * p.K * 2;
+    if (xb >= 0xffffffffull) return imd_set_error("row_linear: operand larger than 4 GiB");
+    p.x_bytes = (uint32_t)xb;
+    p.w_bytes = (uint32_t)wb;
+    p.split_k = 1;
+    p.flags = 0;
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    if (ln) return h ? launch_rl_n<true, true>(p, ln_eps, s) : launch_rl_n<false, true>(p, ln_eps, s);
+    return h ? launch_rl_n<true, false>(p, ln_eps, s) : launch_rl_n<false, false>(p, ln_eps, s);
+}

@@ -108,6 +108,7 @@ def pad64(n: int) -> int:
 # are not listed fall back to the library heuristic.  Key: "M,N,K,taps,stride,ups".
 PATCH_CONV = True          # untabulated 3x3 stride-1 convs on maps >= PATCH_MIN_W wide use the halo-patch kernel (cfg 5)
 PATCH_MIN_W = 32
+FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 _GEMM_TABLE = None
 
@@ -134,7 +135,7 @@ def conv_gemm(
     rowvec_off: int = 0, res: Optional[torch.Tensor] = None, res_ld: Optional[int] = None, out_scale: float = 1.0,
     act: int = ACT_NONE, out_f32: bool = False,
     heads: Optional[dict] = None, cfg: int = -1, split_k: int = 0,
-    gn: Optional[tuple] = None, pad_br_only: bool = False,
+    gn: Optional[tuple] = None, pad_br_only: bool = False, ln_eps: Optional[float] = None,
 ) -> Optional[torch.Tensor]:
     """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
 
@@ -142,6 +143,8 @@ def conv_gemm(
     epilogue (no ``out``).  Returns the output tensor (allocated when ``out`` is None).
     ``gn`` = (coef_a [B, Cin] fp32, coef_b [B, Cin] fp32, silu) from :func:`group_norm_coeffs` fuses GroupNorm(+SiLU)
     of the input into the 3x3 halo-patch kernel (tile config 5).
+    ``ln_eps``: LayerNorm WITHOUT affine over the K channels of every row of ``x`` is applied on the fly (row-resident kernel,
+    K = 320 and N <= 320 only; fold gamma / beta into ``w`` / ``bias`` with :func:`fold_layernorm_affine`).
     """
     ensure_device(x.device)
     K = taps * Cin
@@ -188,6 +191,10 @@ def conv_gemm(
         p.gn_a, p.gn_b, p.gn_silu = _dev(gn[0], torch.float32, "gn_a"), _dev(gn[1], torch.float32, "gn_b"), int(gn[2])
         if cfg == -1:
             cfg = 5
+    if ln_eps is not None:
+        p.split_k = 1
+        L.check(lib.imd_row_linear(C.byref(p), 1, float(ln_eps), _stream()))
+        return out
     splittable = heads is None and act != ACT_GEGLU
     if GEMM_TRACE is not None:
         GEMM_TRACE.append(dict(M=M, N=N, K=K, Cin=Cin, taps=taps, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride,
@@ -202,6 +209,8 @@ def conv_gemm(
             # the table is keyed by (M, N, K, taps, stride, ups) only: another geometry with the same key (W % 16 != 0,
             # pad_br_only, strided pixels ...) may not qualify for the halo-patch kernel -> back to the library heuristic
             if cfg == 5 and not lib.imd_conv_patch_supported(C.byref(p)):
+                cfg, split_k = -1, 0
+            if cfg == 12 and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
@@ -230,11 +239,22 @@ def splitk_workspace(nfloats: int, device) -> torch.Tensor:
 
 
 def linear(x2d: torch.Tensor, w: torch.Tensor, bias=None, *, res=None, act=ACT_NONE, out_f32=False, out=None,
-           out_ld=None, res_ld=None, cfg=-1, split_k=0) -> torch.Tensor:
+           out_ld=None, res_ld=None, cfg=-1, split_k=0, ln_eps=None) -> torch.Tensor:
     M, K = x2d.shape
     N = w.shape[0]
     return conv_gemm(x2d, w, M=M, N=N, Cin=K, bias=bias, res=res, act=act, out_f32=out_f32, out=out,
-                     out_ld=out_ld, res_ld=res_ld, cfg=cfg, split_k=split_k)
+                     out_ld=out_ld, res_ld=res_ld, cfg=cfg, split_k=split_k, ln_eps=ln_eps)
+
+
+def fold_layernorm_affine(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """(W', b') with  LN_affine(x) @ W^T + b == LN_plain(x) @ W'^T + b':  W' = W diag(gamma) (rounded once to the weight dtype),
+    b' = b + W beta (fp32).  Host-side, once per layer (``ln_eps`` of :func:`conv_gemm`)."""
+    wf = w.float()
+    w2 = (wf * gamma.float()[None, :]).to(w.dtype).contiguous()
+    b2 = wf @ beta.float()
+    if bias is not None:
+        b2 = b2 + bias.float()
+    return w2, b2.contiguous()
 
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,

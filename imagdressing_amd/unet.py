@@ -31,6 +31,8 @@ import torch
 from . import ops
 from .hub import PretrainedMixin
 
+FUSED_LN_CHANNELS = 320     # csrc/row_linear.hip: the channel count the fused LayerNorm -> linear kernel exists for
+
 bf16 = torch.bfloat16
 
 SD15_CONFIG = dict(
@@ -241,8 +243,19 @@ class Attention:
     def set_processor(self, p):
         self.processor = p
 
-    def __call__(self, hidden_states, encoder_hidden_states=None, residual=None, **cross_attention_kwargs):
+    def __call__(self, hidden_states, encoder_hidden_states=None, residual=None, layernorm=None, **cross_attention_kwargs):
+        """``layernorm`` = (NormParams, eps): ``hidden_states`` is the block's un-normalised state.  Processors of this
+        package that declare ``fused_layernorm`` run the norm inside their Q projection (row-resident kernel, cross-attention
+        on 320 channels); for everything else -- foreign processors included -- it is applied here, so a processor always
+        sees what the diffusers protocol promises unless it opted in."""
         proc = self.processor
+        if layernorm is not None:
+            nrm, eps = layernorm
+            if (getattr(proc, "fused_layernorm", False) and getattr(proc, "fused_residual", False) and encoder_hidden_states is not None
+                    and hidden_states.shape[-1] == FUSED_LN_CHANNELS and ops.FUSED_LN):
+                cross_attention_kwargs = dict(cross_attention_kwargs, imd_layernorm=(nrm.weight, nrm.bias, eps))
+            else:
+                hidden_states = ops.layer_norm(hidden_states, nrm.weight, nrm.bias, eps)
         if getattr(proc, "fused_residual", False):
             return proc(self, hidden_states, encoder_hidden_states=encoder_hidden_states, attention_mask=None,
                         imd_residual=residual, **cross_attention_kwargs)
@@ -270,8 +283,7 @@ class TransformerBlock:
     def __call__(self, h, ehs, cak):
         n = ops.layer_norm(h, self.norm1.weight, self.norm1.bias)
         h = self.attn1(n, encoder_hidden_states=None, residual=h, **cak)
-        n = ops.layer_norm(h, self.norm2.weight, self.norm2.bias)
-        h = self.attn2(n, encoder_hidden_states=ehs, residual=h, **cak)
+        h = self.attn2(h, encoder_hidden_states=ehs, residual=h, layernorm=(self.norm2, 1e-5), **cak)
         n = ops.layer_norm(h, self.norm3.weight, self.norm3.bias)
         B, L, Cc = h.shape
         g = ops.linear(n.view(B * L, Cc), self.ff_in.weight, self.ff_in.bias, act=ops.ACT_GEGLU)

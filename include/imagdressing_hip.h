@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 2
+#define IMD_ABI_VERSION 3
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -179,6 +179,14 @@ int imd_groupnorm_workspace_floats(int B, int HW, int C, int G);
 int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* coef_b, void* stream);
 /* 1 iff tile config 5 (LDS-resident halo patch: 3x3, stride 1, H % 8 == 0, W % 16 == 0, Cin % 32 == 0) can run *p. */
 int imd_conv_patch_supported(const imd_conv_gemm_params* p);
+
+/* Row-resident linear layer (row_linear.hip) for the 64x64-level token matrix: K = 320, N = 64..320 in steps of 64, same
+ * parameter block and fused epilogue as imd_conv_gemm (taps = 1; tile config 12 of imd_conv_gemm is this kernel with
+ * ln = 0).  Every wave keeps its 32 token rows in registers, the weights stream through LDS by DMA.  ln != 0: LayerNorm
+ * WITHOUT affine (eps = ln_eps) is applied to each row of x on the fly -- BasicTransformerBlock.norm2 -> attn2.to_q as one
+ * launch; the caller folds the affine part into the layer: W' = W diag(gamma), b' = b + W beta. */
+int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* stream);
+int imd_row_linear_supported(const imd_conv_gemm_params* p);
 
 /* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3; adapter/resampler.py:16,43-44,199. */
 int imd_layernorm(const imd_layernorm_params* p, void* stream);

@@ -95,6 +95,56 @@ def test_linear_split_k(ops, M, N, K, split, cfg, dt):
     assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=split)), "not deterministic"
 
 
+@pytest.mark.parametrize("M,N", [(128, 320), (300, 320), (4096 + 37, 320), (200, 64), (1000, 192), (129, 256)])
+@DTS
+def test_row_linear(ops, M, N, dt):
+    """row-resident kernel (tile config 12: K = 320, rows in registers, weights through the LDS-DMA ring) == x W^T + b (+ res)"""
+    K = 320
+    x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
+    ref = x.float() @ w.float().t() + b
+    assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=12), ref, what="row linear")
+    out = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=12)
+    assert_close(out, ref + res.float(), what="row linear + residual")
+    tiled = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=4)
+    assert_close(out, tiled.float(), atol=2e-2 if dt == bf16 else 4e-3, what="row-resident vs tiled kernel")
+    assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=12)), "not deterministic"
+
+
+@pytest.mark.parametrize("M,N", [(128, 320), (333, 320), (2048 + 5, 320), (260, 128)])
+@DTS
+def test_row_linear_layernorm(ops, M, N, dt):
+    """LayerNorm -> linear as ONE launch (affine folded into the weights) == F.layer_norm + F.linear in fp32"""
+    K = 320
+    x = (rnd(1, M, K) * 1.7 + 0.6 * rnd(5, 1, K)).to(dt)          # per-channel offsets: the mean matters
+    w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N)
+    g = 1.0 + 0.3 * rnd(6, K); be = 0.2 * rnd(7, K)
+    ref = F.linear(F.layer_norm(x.float(), (K,), g, be, 1e-5), w.float(), b)
+    w2, b2 = ops.fold_layernorm_affine(dev(w), dev(b), dev(g), dev(be))
+    out = ops.linear(dev(x), w2, b2, ln_eps=1e-5)
+    assert_close(out, ref, atol=3e-2 if dt == bf16 else None, what="LN + linear (fused)")
+    two = ops.linear(ops.layer_norm(dev(x), dev(g), dev(be), 1e-5), dev(w), dev(b))
+    assert_close(out, two.float(), atol=3e-2 if dt == bf16 else 5e-3, what="fused vs two launches")
+
+
+@DTS
+def test_row_linear_head_split(ops, dt):
+    """head-split Q epilogue of the row-resident kernel (norm2 -> attn2.to_q of the 64x64 level: 8 heads x 40)"""
+    B, HW, Cc, H, D = 2, 200, 320, 8, 40
+    DPK, _ = ops.attn_padded_dims(D)
+    x = rnd(1, B * HW, Cc).to(dt); w = rnd(2, Cc, Cc, scale=Cc ** -0.5).to(dt)
+    g = 1.0 + 0.3 * rnd(6, Cc); be = 0.2 * rnd(7, Cc)
+    q = torch.zeros(B, H, HW, DPK, dtype=dt, device="cuda")
+    w2, b2 = ops.fold_layernorm_affine(dev(w), None, dev(g), dev(be))
+    heads = dict(C=Cc, H=H, D=D, dests=[(q, 0, DPK, HW, 0.5)])
+    ops.conv_gemm(dev(x), w2, M=B * HW, N=Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, bias=b2, heads=heads, ln_eps=1e-5)
+    ref = 0.5 * F.linear(F.layer_norm(x.float(), (Cc,), g, be, 1e-5), w.float())
+    ref = ref.view(B, HW, H, D).permute(0, 2, 1, 3)
+    assert_close(q[..., :D], ref, what="LN + to_q head split")
+    assert float(q[..., D:].abs().max()) == 0.0
+    with pytest.raises(ops.L.ImdError):
+        ops.linear(dev(rnd(1, 64, 640).to(dt)), dev(rnd(2, 320, 640).to(dt)), cfg=12)       # K != 320: refused, no fallback
+
+
 @DTS
 def test_conv_auto_split_small_m(ops, dt):
     """the 8x8 ResNet conv shape (M = 512, K = 11520) takes the automatic split-K path"""
