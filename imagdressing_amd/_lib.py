@@ -35,6 +35,12 @@ class ConvGemmParams(C.Structure):
     ]
 
 
+class FfParams(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p),
+                ("M", C.c_int), ("C", C.c_int), ("inner", C.c_int), ("x_ld", C.c_int), ("out_ld", C.c_int), ("ln", C.c_int),
+                ("ln_eps", C.c_float), ("dtype", C.c_int)]
+
+
 class AttnParams(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("k1", C.c_void_p), ("v1t", C.c_void_p), ("k2", C.c_void_p), ("v2t", C.c_void_p),
@@ -90,6 +96,7 @@ SYMBOLS = {
     "imd_conv_patch_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_row_linear": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int, C.c_float, C.c_void_p]),
     "imd_row_linear_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
+    "imd_ff_geglu": (C.c_int, [C.POINTER(FfParams), C.c_void_p]),
     "imd_groupnorm_workspace_floats": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "imd_layernorm": (C.c_int, [C.POINTER(LayerNormParams), C.c_void_p]),
     "imd_softmax_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -128,6 +128,12 @@ int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* st
     return imd_launch_row_linear(*p, ln, ln_eps, (hipStream_t)stream);
 }
 
+int imd_ff_geglu(const imd_ff_params* p, void* stream) {
+    IMD_REQUIRE(p && p->x && p->w1 && p->b1 && p->w2 && p->b2 && p->out, "ff_geglu: null pointer");
+    IMD_REQUIRE(!p->ln || p->ln_eps > 0.f, "ff_geglu: LayerNorm needs eps > 0");
+    return imd_launch_ff_geglu(*p, (hipStream_t)stream);
+}
+
 int imd_layernorm(const imd_layernorm_params* p, void* stream) {
     IMD_REQUIRE(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
     return imd_launch_layernorm(*p, (hipStream_t)stream);

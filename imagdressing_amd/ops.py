@@ -257,6 +257,49 @@ def fold_layernorm_affine(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: 
     return w2, b2.contiguous()
 
 
+def pack_ff_fused(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, gamma: Optional[torch.Tensor] = None,
+                  beta: Optional[torch.Tensor] = None, dtype=None):
+    """Operands of :func:`ff_geglu_fused` from the diffusers-layout FeedForward parameters: ``w1`` [2*inner, C] / ``b1`` =
+    ff.net.0.proj (rows [0, inner) = value, [inner, 2*inner) = gate: ``hidden, gate = proj(x).chunk(2, -1)``), ``w2`` [C, inner] /
+    ``b2`` = ff.net.2; ``gamma`` / ``beta`` = norm3, folded into w1 / b1 (the kernel normalises without affine).  Layout: see
+    include/imagdressing_hip.h::imd_ff_params.  Host-side, once per layer."""
+    dtype = dtype or w1.dtype
+    inner, C = w2.shape[1], w2.shape[0]
+    w1f, b1f = w1.float(), b1.float()
+    if gamma is not None:
+        b1f = b1f + w1f @ beta.float()
+        w1f = w1f * gamma.float()[None, :]
+    dev = w1.device
+    i = torch.arange(32, device=dev)
+    jj = (i & 7) + 8 * (i >> 4)                                  # inner channel of packed row i inside its 16-block
+    gate = ((i >> 3) & 1).bool()
+    blk = torch.arange(inner // 16, device=dev)
+    src = 16 * blk[:, None] + jj[None, :] + torch.where(gate, inner, 0)[None, :]          # [blocks, 32] rows of w1
+    w1p = w1f[src.reshape(-1)].to(dtype).contiguous()            # [blocks * 32, C]
+    b1p = b1f[src.reshape(-1)].contiguous()
+    ks = torch.arange(16, device=dev)
+    jk = torch.where(ks < 4, ks, torch.where(ks < 8, ks + 4, torch.where(ks < 12, ks - 4, ks)))     # slot -> inner channel in the 16-group
+    cols = (16 * torch.arange(inner // 16, device=dev)[:, None] + jk[None, :]).reshape(inner // 32, 32)     # [chunks, 32]
+    w2p = w2.float()[:, cols].permute(1, 0, 2).to(dtype).contiguous()                     # [chunks, C, 32]
+    return dict(w1=w1p, b1=b1p, w2=w2p, b2=b2.float().contiguous(), ln=gamma is not None, C=C, inner=inner)
+
+
+def ff_geglu_fused(x2d: torch.Tensor, packed: dict, ln_eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x + b2 + W2 geglu(W1 LN(x) + b1) in one launch (include/imagdressing_hip.h::imd_ff_geglu; C = 320, inner = 1280)."""
+    ensure_device(x2d.device)
+    M, C_ = x2d.shape
+    dt = x2d.dtype
+    if out is None:
+        out = torch.empty((M, C_), dtype=dt, device=x2d.device)
+    p = L.FfParams()
+    p.x, p.w1, p.b1 = _dev(x2d, dt, "x"), _dev(packed["w1"], dt, "w1"), _dev(packed["b1"], torch.float32, "b1")
+    p.w2, p.b2, p.out = _dev(packed["w2"], dt, "w2"), _dev(packed["b2"], torch.float32, "b2"), _dev(out, dt, "out")
+    p.M, p.C, p.inner, p.x_ld, p.out_ld = M, packed["C"], packed["inner"], x2d.stride(0), out.stride(0)
+    p.ln, p.ln_eps, p.dtype = int(packed["ln"]), float(ln_eps), _code(x2d, "x")
+    L.check(L.load().imd_ff_geglu(C.byref(p), _stream()))
+    return out
+
+
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
                 rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0, gn=None,
                 pad_br_only=False) -> torch.Tensor:

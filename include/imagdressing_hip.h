@@ -94,6 +94,28 @@ typedef struct imd_attn_params {
                           * guarantee the d = 40 kernel may stage K / V^T by LDS-DMA, which cannot patch data in flight. */
 } imd_attn_params;
 
+/* Fused feed-forward of a transformer block on the 64x64 level (ff_fused.hip), C = 320, inner = 1280:
+ *   out = x + b2 + W2 . geglu(W1 . LN(x) + b1)         (norm3 -> ff.net[0] GEGLU -> ff.net[2] -> + residual, ONE launch)
+ * w1 / b1 / w2 are PACKED by the host (imagdressing_amd/ops.py::pack_ff_fused; layout documented there and in ff_fused.hip):
+ *   w1 [80 blocks][32 rows][320]: block b holds inner channels 16 b .. 16 b + 15; row i is the value row (bit 3 of i clear)
+ *      or the gate row (bit 3 set) of inner channel 16 b + (i & 7) + 8 (i >> 4); LayerNorm gamma folded in (W1 diag(gamma));
+ *   b1 [80][32] fp32 in the same order, LayerNorm beta folded in (b1 + W1 beta);
+ *   w2 [40 chunks][320 rows][32]: chunk c holds inner channels 32 c .. 32 c + 31 as two 16-groups whose members are stored in
+ *      the order 0-3, 8-11, 4-7, 12-15 (the register order of the GEGLU outputs of a lane). */
+typedef struct imd_ff_params {
+    const uint16_t* x;   /* [M, x_ld] block input (un-normalised when ln) -- also the residual */
+    const uint16_t* w1;
+    const float* b1;
+    const uint16_t* w2;
+    const float* b2;     /* [C] */
+    uint16_t* out;       /* [M, out_ld] */
+    int M, C, inner;
+    int x_ld, out_ld;
+    int ln;              /* 1: LayerNorm without affine (eps = ln_eps) on every row of x first */
+    float ln_eps;
+    int dtype;
+} imd_ff_params;
+
 typedef struct imd_groupnorm_params {
     const uint16_t* x; uint16_t* y; const float* gamma; const float* beta;
     float* partial;      /* workspace of imd_groupnorm_workspace_floats() floats */
@@ -187,6 +209,9 @@ int imd_conv_patch_supported(const imd_conv_gemm_params* p);
  * launch; the caller folds the affine part into the layer: W' = W diag(gamma), b' = b + W beta. */
 int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* stream);
 int imd_row_linear_supported(const imd_conv_gemm_params* p);
+
+/* BasicTransformerBlock.norm3 + ff (GEGLU feed-forward) + residual as one launch; see imd_ff_params. */
+int imd_ff_geglu(const imd_ff_params* p, void* stream);
 
 /* LayerNorm over the last dim: BasicTransformerBlock.norm1/2/3; adapter/resampler.py:16,43-44,199. */
 int imd_layernorm(const imd_layernorm_params* p, void* stream);

@@ -56,7 +56,8 @@ def header_struct_fields(name):
 
 @pytest.mark.parametrize("cname,pyname", [("imd_heads_dest", "HeadsDest"), ("imd_conv_gemm_params", "ConvGemmParams"),
                                           ("imd_attn_params", "AttnParams"), ("imd_groupnorm_params", "GroupNormParams"),
-                                          ("imd_layernorm_params", "LayerNormParams"), ("imd_ddim_params", "DdimParams")])
+                                          ("imd_layernorm_params", "LayerNormParams"), ("imd_ddim_params", "DdimParams"),
+                                          ("imd_ff_params", "FfParams")])
 def test_struct_layout_matches_header(cname, pyname):
     from imagdressing_amd import _lib
     py = [f[0] for f in getattr(_lib, pyname)._fields_]

@@ -145,6 +145,32 @@ def test_row_linear_head_split(ops, dt):
         ops.linear(dev(rnd(1, 64, 640).to(dt)), dev(rnd(2, 320, 640).to(dt)), cfg=12)       # K != 320: refused, no fallback
 
 
+@pytest.mark.parametrize("M,ln", [(128, True), (300, True), (2048 + 77, True), (256, False)])
+@DTS
+def test_ff_geglu_fused(ops, M, ln, dt):
+    """norm3 -> GEGLU feed-forward -> + residual as one launch == the fp32 restatement of diffusers' FeedForward(geglu)"""
+    Cc, inner = 320, 1280
+    x = (rnd(1, M, Cc) * 1.3 + 0.5 * rnd(5, 1, Cc)).to(dt)
+    w1 = rnd(2, 2 * inner, Cc, scale=Cc ** -0.5).to(dt); b1 = 0.3 * rnd(3, 2 * inner)
+    w2 = rnd(4, Cc, inner, scale=inner ** -0.5).to(dt); b2 = 0.3 * rnd(8, Cc)
+    g = 1.0 + 0.3 * rnd(6, Cc); be = 0.2 * rnd(7, Cc)
+    xf = x.float()
+    n = F.layer_norm(xf, (Cc,), g, be, 1e-5) if ln else xf
+    hid, gate = F.linear(n, w1.float(), b1).chunk(2, dim=-1)
+    ref = xf + F.linear(hid * F.gelu(gate), w2.float(), b2)
+    packed = ops.pack_ff_fused(dev(w1), dev(b1), dev(w2), dev(b2), dev(g) if ln else None, dev(be) if ln else None)
+    out = ops.ff_geglu_fused(dev(x), packed, 1e-5)
+    assert out.dtype == dt
+    assert_close(out, ref, atol=4e-2 if dt == bf16 else 6e-3, rtol=2e-2 if dt == bf16 else 3e-3, what="fused feed-forward")
+    # against the three-launch path of the engine (interleaved GEGLU rows)
+    wi = torch.stack([w1[:inner], w1[inner:]], dim=1).reshape(2 * inner, Cc); bi = torch.stack([b1[:inner], b1[inner:]], dim=1).reshape(-1)
+    nn_ = ops.layer_norm(dev(x), dev(g), dev(be), 1e-5) if ln else dev(x)
+    gg = ops.linear(nn_, dev(wi), dev(bi), act=ops.ACT_GEGLU)
+    three = ops.linear(gg, dev(w2), dev(b2), res=dev(x))
+    assert_close(out, three.float(), atol=5e-2 if dt == bf16 else 8e-3, rtol=2e-2 if dt == bf16 else 3e-3, what="fused vs three launches")
+    assert torch.equal(out, ops.ff_geglu_fused(dev(x), packed, 1e-5)), "not deterministic"
+
+
 @DTS
 def test_conv_auto_split_small_m(ops, dt):
     """the 8x8 ResNet conv shape (M = 512, K = 11520) takes the automatic split-K path"""
