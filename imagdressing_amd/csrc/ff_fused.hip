@@ -23,6 +23,7 @@
 //     FF2(c - 1) -- so there is ONE barrier per chunk and the GELU VALU work sits next to independent MFMAs.
 // Arithmetic is that of the unfused path: h is rounded to the 16-bit element type before the second GEMM (as the GEGLU tensor
 // was when it went through memory), fp32 accumulation everywhere, erf-based GELU (common.h).
+#include <type_traits>
 #include "gemm_common.h"
 #include "lds_dma.h"
 
@@ -157,41 +158,42 @@ __global__ __launch_bounds__(512, 1) void ff_geglu320_kernel(const imd_ff_params
     const float* b1s = reinterpret_cast<const float*>(smem + FF_OFF_B1);
     uint4 h_own = make_uint4(0, 0, 0, 0);
 
-#pragma unroll 1
-    for (int c = 0; c <= FF_NCH; ++c) {
+    // one chunk step: FF1(c) (DO1) and FF2(c - 1) (DO2) with their MFMAs interleaved 2 : 1 -- the first GEMM is a single
+    // dependent accumulator chain, the second brings five independent ones -- then the GELU of chunk c
+    auto step = [&](int c, auto do1, auto do2) {
+        constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
         dma_wait();                      // W1(c) and W2(c - 1), requested one iteration ago, have landed (this wave's pieces)
         __syncthreads();                 // ... everybody's; h(c - 1) is published; the slots of W1(c - 1) / W2(c - 2) are free
-        if (c + 1 < FF_NCH) stage_w1(c + 1);
-        if (c < FF_NCH) stage_w2(c);
-
-        if (c > 0) {                     // second GEMM over the 32 inner channels of chunk c - 1
-            const uint4 h_par = hx[((c - 1) & 1) * 512 + (wave ^ 4) * 64 + lane];
-            const char* W2s = w2lane + ((c - 1) & 1) * FF_W2_CHUNK;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint4 hB = (t == hh) ? h_own : h_par;
-                const uint32_t po = (((uint32_t)(2 * t + hi)) ^ w2sw) << 4;
-#pragma unroll
-                for (int cb = 0; cb < 5; ++cb) {
-                    const uint4 wf = *reinterpret_cast<const uint4*>(W2s + cb * 2048 + po);
-                    acc_out[cb] = E::mfma(wf, hB, acc_out[cb]);
-                }
-            }
-        }
-        if (c < FF_NCH) {                // first GEMM: this wave's 16-channel block (32 packed rows) of chunk c, then GEGLU
-            f32x16 ah;
+        if (DO1 && c + 1 < FF_NCH) stage_w1(c + 1);
+        if (DO1) stage_w2(c);
+        uint4 h_par = make_uint4(0, 0, 0, 0);
+        if (DO2) h_par = hx[((c - 1) & 1) * 512 + (wave ^ 4) * 64 + lane];
+        const char* W2s = w2lane + ((c - 1) & 1) * FF_W2_CHUNK;
+        const uint4 hB0 = hh == 0 ? h_own : h_par, hB1 = hh == 0 ? h_par : h_own;
+        const uint32_t po0 = (((uint32_t)hi) ^ w2sw) << 4, po1 = (((uint32_t)(2 + hi)) ^ w2sw) << 4;
+        f32x16 ah;
+        if (DO1) {
             const float* bb = b1s + (2 * c + hh) * 32 + 4 * hi;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 b = *reinterpret_cast<const float4*>(bb + 8 * q);
                 ah[4 * q] = b.x; ah[4 * q + 1] = b.y; ah[4 * q + 2] = b.z; ah[4 * q + 3] = b.w;
             }
-            const char* W1s = w1lane + (c & 1) * FF_W1_CHUNK;
+        }
+        const char* W1s = w1lane + (c & 1) * FF_W1_CHUNK;
 #pragma unroll
-            for (int s = 0; s < FF_STEPS; ++s) {
+        for (int s = 0; s < FF_STEPS; ++s) {
+            if (DO1) {
                 const uint4 wf = *reinterpret_cast<const uint4*>(W1s + ((uint32_t)(s * 32) ^ a16));
                 ah = E::mfma(wf, xf[s], ah);
             }
+            if (DO2 && (s & 1)) {
+                const int i = s >> 1, t = i / 5, cb = i - 5 * t;          // ten MFMAs of the second GEMM, one per two k-steps
+                const uint4 wf = *reinterpret_cast<const uint4*>(W2s + cb * 2048 + (t ? po1 : po0));
+                acc_out[cb] = E::mfma(wf, t ? hB1 : hB0, acc_out[cb]);
+            }
+        }
+        if (DO1) {
             float h[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -201,7 +203,11 @@ __global__ __launch_bounds__(512, 1) void ff_geglu320_kernel(const imd_ff_params
             h_own = pack8<F16>(h);
             hx[(c & 1) * 512 + wave * 64 + lane] = h_own;
         }
-    }
+    };
+    step(0, std::true_type{}, std::false_type{});
+#pragma unroll 1
+    for (int c = 1; c < FF_NCH; ++c) step(c, std::true_type{}, std::true_type{});
+    step(FF_NCH, std::false_type{}, std::true_type{});
 
     // ---- epilogue: + b2 + residual (the un-normalised input rows, re-read in accumulator layout), 8-byte stores ----
     const float* b2s = reinterpret_cast<const float*>(smem + FF_OFF_B2);

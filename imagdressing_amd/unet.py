@@ -279,13 +279,20 @@ class TransformerBlock:
         bi = torch.stack([b[:inner], b[inner:]], dim=1).reshape(2 * inner)
         self.ff_in = LinearOp(wi, bi, device, dtype)
         self.ff_out = LinearOp(sd[f"{p}.ff.net.2.weight"], sd[f"{p}.ff.net.2.bias"], device, dtype)
+        # 64x64 level (C = 320): norm3 -> GEGLU feed-forward -> + residual as ONE launch (csrc/ff_fused.hip); operands packed once
+        self.ff_fused = None
+        if ch == FUSED_LN_CHANNELS and inner == 4 * ch:
+            self.ff_fused = ops.pack_ff_fused(w.to(device), b.to(device), sd[f"{p}.ff.net.2.weight"].to(device),
+                                              sd[f"{p}.ff.net.2.bias"].to(device), self.norm3.weight, self.norm3.bias, dtype=dtype)
 
     def __call__(self, h, ehs, cak):
         n = ops.layer_norm(h, self.norm1.weight, self.norm1.bias)
         h = self.attn1(n, encoder_hidden_states=None, residual=h, **cak)
         h = self.attn2(h, encoder_hidden_states=ehs, residual=h, layernorm=(self.norm2, 1e-5), **cak)
-        n = ops.layer_norm(h, self.norm3.weight, self.norm3.bias)
         B, L, Cc = h.shape
+        if self.ff_fused is not None and ops.FUSED_FF and B * L >= ops.FUSED_FF_MIN_ROWS:
+            return ops.ff_geglu_fused(h.view(B * L, Cc), self.ff_fused, 1e-5).view(B, L, Cc)
+        n = ops.layer_norm(h, self.norm3.weight, self.norm3.bias)
         g = ops.linear(n.view(B * L, Cc), self.ff_in.weight, self.ff_in.bias, act=ops.ACT_GEGLU)
         return ops.linear(g, self.ff_out.weight, self.ff_out.bias, res=h.view(B * L, Cc)).view(B, L, Cc)
 

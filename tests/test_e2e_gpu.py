@@ -52,6 +52,24 @@ def test_unet_forward_small(small_pair):
 
 
 @torch.no_grad()
+def test_unet_forward_small_fused_feed_forward(small_pair, monkeypatch):
+    """the 320-channel blocks with norm3 -> GEGLU feed-forward -> + residual as ONE launch (ff_fused.hip; the engines use it from
+    16384 rows up, here forced on) against the oracle, and against the four-launch path"""
+    from imagdressing_amd import ops
+    p = small_pair
+    x = g(1, 2, 4, 16, 16); ehs = g(2, 2, 77, 64, scale=0.5)
+    ref = p["o_unet"](x, 481, ehs)
+    monkeypatch.setattr(ops, "FUSED_FF_MIN_ROWS", 0)
+    got = p["e_unet"](x.cuda(), 481, ehs.cuda())[0]
+    monkeypatch.setattr(ops, "FUSED_FF", False)
+    plain = p["e_unet"](x.cuda(), 481, ehs.cuda())[0]
+    assert not torch.equal(got, plain)                   # the fused kernel really ran
+    st = err_stats(got, ref); record(f"unet_forward_small_fused_ff[{p['dtype']}]", st)
+    bar = BARS[p["dtype"]]
+    assert st["max_abs"] < bar["max_abs"] and st["rel_rms"] < bar["rel_rms"], st
+
+
+@torch.no_grad()
 def test_unet_forward_small_with_garment(small_pair):
     from oracle.pipeline import garment_features
     p = small_pair
