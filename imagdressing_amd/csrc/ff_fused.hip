@@ -158,17 +158,22 @@ __global__ __launch_bounds__(512, 1) void ff_geglu320_kernel(const imd_ff_params
     const float* b1s = reinterpret_cast<const float*>(smem + FF_OFF_B1);
     uint4 h_own = make_uint4(0, 0, 0, 0);
 
-    // one chunk step: FF1(c) (DO1) and FF2(c - 1) (DO2) with their MFMAs interleaved 2 : 1 -- the first GEMM is a single
-    // dependent accumulator chain, the second brings five independent ones -- then the GELU of chunk c
-    auto step = [&](int c, auto do1, auto do2) {
-        constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
-        dma_wait();                      // W1(c) and W2(c - 1), requested one iteration ago, have landed (this wave's pieces)
-        __syncthreads();                 // ... everybody's; h(c - 1) is published; the slots of W1(c - 1) / W2(c - 2) are free
+    // one chunk step, three stages deep: FF1(c) (DO1), the GELU of chunk c - 1 (DOG) and FF2(c - 2) (DO2).  The first GEMM is
+    // a single dependent accumulator chain and the GELU is ~130 VALU instructions per wave: written out interleaved (two
+    // first-GEMM MFMAs, one second-GEMM MFMA, one GELU) so that the VALU work issues in the shadow of independent MFMAs
+    // instead of between the barrier and the next chunk (measured: GELU 32 us, first GEMM 40 us, second 24 us, all additive).
+    f32x16 ahp;                      // first-GEMM result of the previous chunk, waiting for its GELU
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ahp[r] = 0.f;
+    auto step = [&](int c, auto do1, auto dog, auto do2) {
+        constexpr bool DO1 = decltype(do1)::value, DOG = decltype(dog)::value, DO2 = decltype(do2)::value;
+        dma_wait();                      // W1(c) and W2(c - 2), requested one iteration ago, have landed (this wave's pieces)
+        __syncthreads();                 // ... everybody's; h(c - 2) is published; the slots of W1(c - 1) / W2(c - 3) are free
         if (DO1 && c + 1 < FF_NCH) stage_w1(c + 1);
-        if (DO1) stage_w2(c);
+        if (DOG) stage_w2(c - 1);        // needed by FF2(c - 1) in the next iteration
         uint4 h_par = make_uint4(0, 0, 0, 0);
-        if (DO2) h_par = hx[((c - 1) & 1) * 512 + (wave ^ 4) * 64 + lane];
-        const char* W2s = w2lane + ((c - 1) & 1) * FF_W2_CHUNK;
+        if (DO2) h_par = hx[(c & 1) * 512 + (wave ^ 4) * 64 + lane];
+        const char* W2s = w2lane + (c & 1) * FF_W2_CHUNK;
         const uint4 hB0 = hh == 0 ? h_own : h_par, hB1 = hh == 0 ? h_par : h_own;
         const uint32_t po0 = (((uint32_t)hi) ^ w2sw) << 4, po1 = (((uint32_t)(2 + hi)) ^ w2sw) << 4;
         f32x16 ah;
@@ -181,33 +186,47 @@ __global__ __launch_bounds__(512, 1) void ff_geglu320_kernel(const imd_ff_params
             }
         }
         const char* W1s = w1lane + (c & 1) * FF_W1_CHUNK;
+        float h[8];
+        // Slot schedule, pinned with sched_barrier(0) (left alone hipcc issues the 30 MFMAs first, each behind the wait for its
+        // own fragment, and the whole GELU afterwards).  Slot s: fragment reads two slots ahead, first-GEMM MFMA s, on odd slots a
+        // second-GEMM MFMA, on even slots one GELU -- VALU and LDS latency sit in the shadow of MFMAs that do not depend on them.
+        uint4 w1f[3], w2f[2];
+        auto ld1 = [&](int st) { return *reinterpret_cast<const uint4*>(W1s + ((uint32_t)(st * 32) ^ a16)); };
+        auto ld2 = [&](int i) { const int t = i / 5, cb = i - 5 * t; return *reinterpret_cast<const uint4*>(W2s + cb * 2048 + (t ? po1 : po0)); };
+        if (DO1) { w1f[0] = ld1(0); w1f[1] = ld1(1); }
+        if (DO2) w2f[0] = ld2(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < FF_STEPS; ++s) {
-            if (DO1) {
-                const uint4 wf = *reinterpret_cast<const uint4*>(W1s + ((uint32_t)(s * 32) ^ a16));
-                ah = E::mfma(wf, xf[s], ah);
-            }
+            if (DO1 && s + 2 < FF_STEPS) w1f[(s + 2) % 3] = ld1(s + 2);
+            if (DO1) ah = E::mfma(w1f[s % 3], xf[s], ah);
             if (DO2 && (s & 1)) {
                 const int i = s >> 1, t = i / 5, cb = i - 5 * t;          // ten MFMAs of the second GEMM, one per two k-steps
-                const uint4 wf = *reinterpret_cast<const uint4*>(W2s + cb * 2048 + (t ? po1 : po0));
-                acc_out[cb] = E::mfma(wf, t ? hB1 : hB0, acc_out[cb]);
+                if (i + 1 < 10) w2f[(i + 1) & 1] = ld2(i + 1);
+                acc_out[cb] = E::mfma(w2f[i & 1], t ? hB1 : hB0, acc_out[cb]);
             }
+            if (DOG && !(s & 1) && s < 16) {                              // eight GELUs, one per two k-steps
+                const int e = s >> 1;
+                float gate = e < 4 ? ahp[4 + e] : ahp[8 + e];
+                asm volatile("" : "+v"(gate));                            // opaque: the GELU may neither be hoisted to the top ...
+                h[e] = (e < 4 ? ahp[e] : ahp[4 + e]) * gelu_erf_f(gate);
+                asm volatile("" : "+v"(h[e]));                            // ... nor sunk below the last MFMA (pure VALU floats across sched_barrier)
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (DO1) {
-            float h[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                h[e] = ah[e] * gelu_erf_f(ah[4 + e]);
-                h[4 + e] = ah[8 + e] * gelu_erf_f(ah[12 + e]);
-            }
+        if (DOG) {                       // h(c - 1): own half stays in registers for FF2(c - 1), the partner finds it in LDS
             h_own = pack8<F16>(h);
-            hx[(c & 1) * 512 + wave * 64 + lane] = h_own;
+            hx[((c - 1) & 1) * 512 + wave * 64 + lane] = h_own;
         }
+        if (DO1) ahp = ah;
     };
-    step(0, std::true_type{}, std::false_type{});
+    using T_ = std::true_type; using F_ = std::false_type;
+    step(0, T_{}, F_{}, F_{});
+    step(1, T_{}, T_{}, F_{});
 #pragma unroll 1
-    for (int c = 1; c < FF_NCH; ++c) step(c, std::true_type{}, std::true_type{});
-    step(FF_NCH, std::false_type{}, std::true_type{});
+    for (int c = 2; c < FF_NCH; ++c) step(c, T_{}, T_{}, T_{});
+    step(FF_NCH, F_{}, T_{}, T_{});
+    step(FF_NCH + 1, F_{}, F_{}, T_{});
 
     // ---- epilogue: + b2 + residual (the un-normalised input rows, re-read in accumulator layout), 8-byte stores ----
     const float* b2s = reinterpret_cast<const float*>(smem + FF_OFF_B2);

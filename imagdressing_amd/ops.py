@@ -109,7 +109,7 @@ def pad64(n: int) -> int:
 PATCH_CONV = True          # untabulated 3x3 stride-1 convs on maps >= PATCH_MIN_W wide use the halo-patch kernel (cfg 5)
 PATCH_MIN_W = 32
 FUSED_FF = True            # engines run norm3 -> GEGLU feed-forward -> + residual of the 320-channel blocks as one launch (ff_fused.hip)
-FUSED_FF_MIN_ROWS = 16384  # below this the 128-row workgroups cannot fill the chip (one per CU at 32768 rows) and the tiled kernels win
+FUSED_FF_MIN_ROWS = 24576  # below this the 128-row workgroups cannot fill the chip (one per CU at 32768 rows) and the tiled kernels win
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 _GEMM_TABLE = None
