@@ -151,8 +151,9 @@ def _ln_folded_q(attn, gamma: torch.Tensor, beta: torch.Tensor, dtype, device):
     return ent[2]
 
 
-# channel count the row-resident ``LayerNorm -> linear`` kernel exists for (csrc/row_linear.hip: the 64x64 level of SD1.5)
-FUSED_LN_CHANNELS = 320
+# channel counts the row-resident ``LayerNorm -> linear`` kernels exist for (csrc/row_linear.hip, row_linear_k640.hip: the 64x64 and
+# 32x32 levels of SD1.5)
+FUSED_LN_CHANNELS = (320, 640)
 
 
 def _as_tokens(hidden_states: torch.Tensor, dtype):
@@ -304,7 +305,7 @@ class AttnProcessor2_0(_FusedBase):
         q_ln = None
         if imd_layernorm is not None:
             g, be, eps = imd_layernorm
-            if encoder_hidden_states is not None and x.shape[-1] == FUSED_LN_CHANNELS:
+            if encoder_hidden_states is not None and x.shape[-1] in FUSED_LN_CHANNELS:
                 q_ln = _ln_folded_q(attn, g, be, dt, dev) + (eps,)
             else:
                 x = ops.layer_norm(x, g, be, eps)

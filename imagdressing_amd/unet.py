@@ -31,7 +31,7 @@ import torch
 from . import ops
 from .hub import PretrainedMixin
 
-FUSED_LN_CHANNELS = 320     # csrc/row_linear.hip: the channel count the fused LayerNorm -> linear kernel exists for
+FUSED_LN_CHANNELS = (320, 640)     # csrc/row_linear.hip, row_linear_k640.hip: channel counts the fused LayerNorm -> linear kernels exist for
 
 bf16 = torch.bfloat16
 
@@ -252,7 +252,7 @@ class Attention:
         if layernorm is not None:
             nrm, eps = layernorm
             if (getattr(proc, "fused_layernorm", False) and getattr(proc, "fused_residual", False) and encoder_hidden_states is not None
-                    and hidden_states.shape[-1] == FUSED_LN_CHANNELS and ops.FUSED_LN):
+                    and hidden_states.shape[-1] in FUSED_LN_CHANNELS and ops.FUSED_LN):
                 cross_attention_kwargs = dict(cross_attention_kwargs, imd_layernorm=(nrm.weight, nrm.bias, eps))
             else:
                 hidden_states = ops.layer_norm(hidden_states, nrm.weight, nrm.bias, eps)
@@ -281,7 +281,7 @@ class TransformerBlock:
         self.ff_out = LinearOp(sd[f"{p}.ff.net.2.weight"], sd[f"{p}.ff.net.2.bias"], device, dtype)
         # 64x64 level (C = 320): norm3 -> GEGLU feed-forward -> + residual as ONE launch (csrc/ff_fused.hip); operands packed once
         self.ff_fused = None
-        if ch == FUSED_LN_CHANNELS and inner == 4 * ch:
+        if ch == 320 and inner == 4 * ch:
             self.ff_fused = ops.pack_ff_fused(w.to(device), b.to(device), sd[f"{p}.ff.net.2.weight"].to(device),
                                               sd[f"{p}.ff.net.2.bias"].to(device), self.norm3.weight, self.norm3.bias, dtype=dtype)
 

@@ -16,7 +16,8 @@ def timed(fn, iters=60):
     return round(e0.elapsed_time(e1) * 1e3 / iters, 1)
 
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float16
-M, N, K = 32768, 320, 320
+M, N, K = (32768, 320, 320) if os.environ.get('RL_K', '320') == '320' else (8192, 640, 640)
+TILED, ROW = (4, 12) if K == 320 else (2, 13)
 xs = [torch.randn(M, K, device="cuda").to(dt) for _ in range(6)]
 ws = [(torch.randn(N, K, device="cuda") * K ** -0.5).to(dt) for _ in range(6)]
 rs = [torch.randn(M, N, device="cuda").to(dt) for _ in range(6)]
@@ -24,7 +25,7 @@ b = torch.randn(N, device="cuda"); g = torch.ones(K, device="cuda"); be = torch.
 out = torch.empty(M, N, dtype=dt, device="cuda"); nrm = torch.empty(M, K, dtype=dt, device="cuda")
 i = [0]
 row = {}
-for name, cfg in (("tiled_c4", 4), ("row_c12", 12), ("tiled_c4_b", 4), ("row_c12_b", 12)):
+for name, cfg in (("tiled", TILED), ("row", ROW), ("tiled_b", TILED), ("row_b", ROW)):
     def go():
         j = i[0] % 6; i[0] += 1
         ops.linear(xs[j], ws[j], b, res=rs[j], out=out, cfg=cfg, split_k=1)
@@ -36,7 +37,7 @@ for name, cfg in (("tiled_c4", 4), ("row_c12", 12), ("tiled_c4_b", 4), ("row_c12
 def two():
     j = i[0] % 6; i[0] += 1
     ops.layer_norm(xs[j], g, be, out=nrm)
-    ops.linear(nrm, ws[j], b, out=out, cfg=4, split_k=1)
+    ops.linear(nrm, ws[j], b, out=out, cfg=TILED, split_k=1)
 def fused():
     j = i[0] % 6; i[0] += 1
     ops.linear(xs[j], ws[j], b, out=out, ln_eps=1e-5)
