@@ -231,7 +231,7 @@ def main():
             for k in ("cfg", "cfg_nosplit"):
                 if ent.get(k) == 12:
                     ent[k] = 4
-                if ent.get(k) == 13:
+                if ent.get(k) in (13, 14):
                     ent[k] = 2
     lat_hw = args.res // 8
     N0 = lat_hw * lat_hw

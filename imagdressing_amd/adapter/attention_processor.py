@@ -153,7 +153,7 @@ def _ln_folded_q(attn, gamma: torch.Tensor, beta: torch.Tensor, dtype, device):
 
 # channel counts the row-resident ``LayerNorm -> linear`` kernels exist for (csrc/row_linear.hip, row_linear_k640.hip: the 64x64 and
 # 32x32 levels of SD1.5)
-FUSED_LN_CHANNELS = (320, 640)
+FUSED_LN_CHANNELS = (320, 640, 1280)
 
 
 def _as_tokens(hidden_states: torch.Tensor, dtype):

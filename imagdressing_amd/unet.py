@@ -31,7 +31,7 @@ import torch
 from . import ops
 from .hub import PretrainedMixin
 
-FUSED_LN_CHANNELS = (320, 640)     # csrc/row_linear.hip, row_linear_k640.hip: channel counts the fused LayerNorm -> linear kernels exist for
+FUSED_LN_CHANNELS = (320, 640, 1280)     # csrc/row_linear.hip, row_linear_k640.hip: channel counts the fused LayerNorm -> linear kernels exist for
 
 bf16 = torch.bfloat16
 

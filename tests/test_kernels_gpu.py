@@ -205,6 +205,40 @@ def test_row_linear_k640_layernorm_head_split(ops, dt):
     assert_close(q[..., :D], ref, atol=2e-2 if dt == bf16 else None, what="LN + to_q head split k640")
 
 
+@pytest.mark.parametrize("M,N", [(64, 1280), (300, 1280), (2048 + 37, 1280), (200, 160), (512, 640)])
+@DTS
+def test_row_linear_k1280(ops, M, N, dt):
+    """4-way split-K row-resident kernel on v_mfma_f32_16x16x32 (tile config 14: K = 1280)"""
+    K = 1280
+    x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
+    ref = x.float() @ w.float().t() + b
+    assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=14), ref, what="row linear k1280")
+    out = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=14)
+    assert_close(out, ref + res.float(), what="row linear k1280 + residual")
+    tiled = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=2)
+    assert_close(out, tiled.float(), atol=2e-2 if dt == bf16 else 4e-3, what="row-resident vs tiled kernel")
+    assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=14)), "not deterministic"
+
+
+@DTS
+def test_row_linear_k1280_layernorm_head_split(ops, dt):
+    """norm2 -> attn2.to_q of the 16x16 level (8 heads x 160) as one launch, head-split Q epilogue; and the row-major LN + linear"""
+    B, HW, Cc, H, D = 2, 200, 1280, 8, 160
+    DPK, _ = ops.attn_padded_dims(D)
+    x = (rnd(1, B * HW, Cc) * 1.5 + 0.6 * rnd(5, 1, Cc)).to(dt); w = rnd(2, Cc, Cc, scale=Cc ** -0.5).to(dt); b = rnd(3, Cc)
+    g = 1.0 + 0.3 * rnd(6, Cc); be = 0.2 * rnd(7, Cc)
+    nref = F.layer_norm(x.float(), (Cc,), g, be, 1e-5)
+    w2, b2 = ops.fold_layernorm_affine(dev(w), dev(b), dev(g), dev(be))
+    out = ops.linear(dev(x), w2, b2, ln_eps=1e-5)
+    assert_close(out, F.linear(nref, w.float(), b), atol=3e-2 if dt == bf16 else None, what="LN + linear k1280")
+    q = torch.zeros(B, H, HW, DPK, dtype=dt, device="cuda")
+    w3, b3 = ops.fold_layernorm_affine(dev(w), None, dev(g), dev(be))
+    ops.conv_gemm(dev(x), w3, M=B * HW, N=Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, bias=b3, ln_eps=1e-5,
+                  heads=dict(C=Cc, H=H, D=D, dests=[(q, 0, DPK, HW, 0.25)]))
+    ref = (0.25 * F.linear(nref, w.float())).view(B, HW, H, D).permute(0, 2, 1, 3)
+    assert_close(q[..., :D], ref, atol=2e-2 if dt == bf16 else None, what="LN + to_q head split k1280")
+
+
 @DTS
 def test_conv_auto_split_small_m(ops, dt):
     """the 8x8 ResNet conv shape (M = 512, K = 11520) takes the automatic split-K path"""

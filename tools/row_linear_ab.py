@@ -16,8 +16,8 @@ def timed(fn, iters=60):
     return round(e0.elapsed_time(e1) * 1e3 / iters, 1)
 
 dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else torch.float16
-M, N, K = (32768, 320, 320) if os.environ.get('RL_K', '320') == '320' else (8192, 640, 640)
-TILED, ROW = (4, 12) if K == 320 else (2, 13)
+M, N, K = {'320': (32768, 320, 320), '640': (8192, 640, 640), '1280': (2048, 1280, 1280)}[os.environ.get('RL_K', '320')]
+TILED, ROW = {320: (4, 12), 640: (2, 13), 1280: (2, 14)}[K]
 xs = [torch.randn(M, K, device="cuda").to(dt) for _ in range(6)]
 ws = [(torch.randn(N, K, device="cuda") * K ** -0.5).to(dt) for _ in range(6)]
 rs = [torch.randn(M, N, device="cuda").to(dt) for _ in range(6)]
