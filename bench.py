@@ -229,7 +229,7 @@ def main():
         ops.FUSED_LN = False
         for ent in ops._gemm_table().values():
             for k in ("cfg", "cfg_nosplit"):
-                if ent.get(k) == 12:
+                if ent.get(k) in (12, 15):
                     ent[k] = 4
                 if ent.get(k) in (13, 14):
                     ent[k] = 2

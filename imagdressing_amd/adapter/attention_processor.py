@@ -138,17 +138,24 @@ def _layer_weights(attn, which: str, dtype, device) -> torch.Tensor:
     return ent[2]
 
 
-def _ln_folded_q(attn, gamma: torch.Tensor, beta: torch.Tensor, dtype, device):
-    """(W_q diag(gamma), W_q beta) for the fused ``LayerNorm -> to_q`` launch (ops.conv_gemm ``ln_eps``), cached on the module
-    against the identity / version of to_q.weight and the two norm parameters."""
-    srcs = (attn.to_q.weight, gamma, beta)
+def _ln_folded_q(attn, gamma: torch.Tensor, beta: torch.Tensor, dtype, device, which: str = "q"):
+    """(W diag(gamma), W beta) for the fused ``LayerNorm -> to_q`` (which = "q") / ``LayerNorm -> to_q, to_k, to_v`` ("qkv")
+    launch (ops.conv_gemm ``ln_eps``), cached on the module against the identity / version of the projection weights and the
+    two norm parameters."""
+    mods = [getattr(attn, n) for n in _W_PARTS[which]]
+    srcs = tuple(m.weight for m in mods) + (gamma, beta)
     cache = attn.__dict__.setdefault("_imd_wcache", {})
     key = (_version_key(*srcs), dtype, str(device))
-    ent = cache.get("q_ln")
+    ent = cache.get(which + "_ln")
     if ent is None or ent[0] != key or not all(a is b for a, b in zip(ent[1], srcs)):
-        w = attn.to_q.weight.detach().to(device=device, dtype=dtype)
-        ent = cache["q_ln"] = (key, srcs, ops.fold_layernorm_affine(w, None, gamma.to(device), beta.to(device)))
+        w = torch.cat([m.weight.detach().to(device=device, dtype=dtype) for m in mods], 0)
+        ent = cache[which + "_ln"] = (key, srcs, ops.fold_layernorm_affine(w, None, gamma.to(device), beta.to(device)))
     return ent[2]
+
+
+# fused ``norm1 -> to_q / to_k / to_v`` (csrc/row_qkv.hip): 320 channels, token count per image a multiple of 128
+def _qkv_ln_ok(x: torch.Tensor) -> bool:
+    return x.shape[-1] == 320 and x.shape[1] % 128 == 0 and ops.FUSED_LN
 
 
 # channel counts the row-resident ``LayerNorm -> linear`` kernels exist for (csrc/row_linear.hip, row_linear_k640.hip: the 64x64 and
@@ -230,8 +237,11 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
         LP = ops.pad64(N)
         k = ops.k_buffer((B, heads, N, dpk), D, dt, dev, tag="attn_k")
         vt = ops.workspace("attn_vt", (B, heads, dpv, LP), dt, dev)
-        ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=3 * Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1,
-                      heads=dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale), (k, 0, dpk, N, 1.0), (vt, 1, dpv, LP, 1.0)]))
+        dests = dict(C=Cc, H=heads, D=D, dests=[(q, 0, dpk, N, qscale), (k, 0, dpk, N, 1.0), (vt, 1, dpv, LP, 1.0)])
+        if q_ln is not None:          # x is the un-normalised block state: norm1 runs inside the projection (row_qkv.hip)
+            ops.conv_gemm(x2, q_ln[0], M=B * N, N=3 * Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1, bias=q_ln[1], ln_eps=q_ln[2], heads=dests)
+        else:
+            ops.conv_gemm(x2, wq_or_qkv, M=B * N, N=3 * Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1, heads=dests)
         kv1, kv1_bdiv = (k, vt, N, LP), 1
     elif q_ln is not None:
         ops.conv_gemm(x2, q_ln[0], M=B * N, N=Cc, Cin=Cc, Hin=N, Win=1, Hout=N, Wout=1, bias=q_ln[1], ln_eps=q_ln[2],
@@ -307,11 +317,13 @@ class AttnProcessor2_0(_FusedBase):
             g, be, eps = imd_layernorm
             if encoder_hidden_states is not None and x.shape[-1] in FUSED_LN_CHANNELS:
                 q_ln = _ln_folded_q(attn, g, be, dt, dev) + (eps,)
+            elif encoder_hidden_states is None and _qkv_ln_ok(x):
+                q_ln = _ln_folded_q(attn, g, be, dt, dev, "qkv") + (eps,)
             else:
                 x = ops.layer_norm(x, g, be, eps)
         if encoder_hidden_states is None:
             out = _fused_attention(x, attn.heads, wq_or_qkv=_layer_weights(attn, "qkv", dt, dev), self_attn=True, wo=wo, bo=bo,
-                                   residual=imd_residual)
+                                   residual=imd_residual, q_ln=q_ln)
         else:
             srcs = (encoder_hidden_states, attn.to_k.weight, attn.to_v.weight)
             kv = self._text.get(srcs, extra=(dt,))
@@ -395,6 +407,7 @@ class _RefMixin:
 class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
     """Hybrid attention: frozen self-attention + trainable garment cross-attention
     (attention_processor.py:513-627)."""
+    fused_layernorm = True      # engine-side opt-in: norm1 may run inside the q / k / v projection (see AttnProcessor2_0)
 
     def __init__(self, name, hidden_size, cross_attention_dim=None, scale=1.0):
         super().__init__()
@@ -405,12 +418,19 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  num_images_per_prompt=1, cond_hidden_states=None, sa_hidden_states=None, sa_batch_mask=None,
-                 imd_residual=None, **kwargs):
+                 imd_residual=None, imd_layernorm=None, **kwargs):
         if encoder_hidden_states is not None:
             raise NotImplementedError(f"{type(self).__name__} is a self-attention (attn1) processor")
         dt = _compute_dtype(attn, hidden_states, attention_mask)
         x, shape4 = _as_tokens(hidden_states, dt)
         wqkv, wo, bo = self._weights(attn, dt, x.device)
+        q_ln = None
+        if imd_layernorm is not None:
+            g, be, eps = imd_layernorm
+            if _qkv_ln_ok(x):
+                q_ln = _ln_folded_q(attn, g, be, dt, x.device, "qkv") + (eps,)
+            else:
+                x = ops.layer_norm(x, g, be, eps)
         kv2 = s2 = None
         bdiv2 = 1
         if sa_hidden_states is not None:                                   # :597
@@ -419,7 +439,7 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
             bdiv2 = self._garment_bdiv(x.shape[0], ref)
             s2 = self._branch_weights(x.shape[0], sa_batch_mask, x.device)
         out = _fused_attention(x, attn.heads, wq_or_qkv=wqkv, self_attn=True, kv2=kv2, kv2_bdiv=bdiv2,
-                               scale2=s2, wo=wo, bo=bo, residual=imd_residual)
+                               scale2=s2, wo=wo, bo=bo, residual=imd_residual, q_ln=q_ln)
         return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
 
 

@@ -112,7 +112,7 @@ int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* co
 
 int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (p && imd_conv_patch_supported(*p)) ? 1 : 0; }
 
-int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (p && (imd_row_linear_supported(*p) || imd_row_linear_k640_supported(*p) || imd_row_linear_k1280_supported(*p))) ? 1 : 0; }
+int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (p && (imd_row_linear_supported(*p) || imd_row_linear_k640_supported(*p) || imd_row_linear_k1280_supported(*p) || imd_row_qkv_supported(*p))) ? 1 : 0; }
 
 int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* stream) {
     IMD_REQUIRE(p != nullptr, "row_linear: null params");
@@ -125,6 +125,7 @@ int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* st
         IMD_REQUIRE(!p->out_f32, "row_linear: head-split output excludes fp32 output");
     }
     IMD_REQUIRE(!ln || ln_eps > 0.f, "row_linear: LayerNorm needs eps > 0");
+    if (p->K == 320 && p->N == 960 && p->mode == IMD_OUT_HEADS) return imd_launch_row_qkv(*p, ln, ln_eps, (hipStream_t)stream);
     if (p->K == 640) return imd_launch_row_linear_k640(*p, ln, ln_eps, (hipStream_t)stream);
     if (p->K == 1280) return imd_launch_row_linear_k1280(*p, ln, ln_eps, (hipStream_t)stream);
     return imd_launch_row_linear(*p, ln, ln_eps, (hipStream_t)stream);

@@ -441,6 +441,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 12: return imd_launch_row_linear(p, 0, 0.f, s);      // row-resident kernel (row_linear.hip): K = 320, N <= 320
         case 13: return imd_launch_row_linear_k640(p, 0, 0.f, s); // row-resident split-K kernel (row_linear_k640.hip): K = 640, N % 160 == 0
         case 14: return imd_launch_row_linear_k1280(p, 0, 0.f, s); // row-resident 4-way split-K kernel (row_linear_k1280.hip): K = 1280, N % 160 == 0
+        case 15: return imd_launch_row_qkv(p, 0, 0.f, s);          // row-resident q/k/v projection of a 320-channel block (row_qkv.hip)
         default: return imd_set_error("conv_gemm: unknown tile config %d", cfg);
     }
 }

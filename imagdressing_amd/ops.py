@@ -212,7 +212,7 @@ def conv_gemm(
             # pad_br_only, strided pixels ...) may not qualify for the halo-patch kernel -> back to the library heuristic
             if cfg == 5 and not lib.imd_conv_patch_supported(C.byref(p)):
                 cfg, split_k = -1, 0
-            if cfg in (12, 13, 14) and not lib.imd_row_linear_supported(C.byref(p)):
+            if cfg in (12, 13, 14, 15) and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)

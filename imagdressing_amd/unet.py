@@ -251,8 +251,11 @@ class Attention:
         proc = self.processor
         if layernorm is not None:
             nrm, eps = layernorm
-            if (getattr(proc, "fused_layernorm", False) and getattr(proc, "fused_residual", False) and encoder_hidden_states is not None
-                    and hidden_states.shape[-1] in FUSED_LN_CHANNELS and ops.FUSED_LN):
+            # cross-attention: norm -> to_q on 320 / 640 / 1280 channels; self-attention: norm -> q / k / v on 320 channels (the
+            # processor falls back to a separate LayerNorm launch for shapes its kernels do not cover)
+            if (getattr(proc, "fused_layernorm", False) and getattr(proc, "fused_residual", False) and ops.FUSED_LN
+                    and (hidden_states.shape[-1] in FUSED_LN_CHANNELS if encoder_hidden_states is not None
+                         else hidden_states.shape[-1] == 320)):
                 cross_attention_kwargs = dict(cross_attention_kwargs, imd_layernorm=(nrm.weight, nrm.bias, eps))
             else:
                 hidden_states = ops.layer_norm(hidden_states, nrm.weight, nrm.bias, eps)
@@ -286,8 +289,7 @@ class TransformerBlock:
                                               sd[f"{p}.ff.net.2.bias"].to(device), self.norm3.weight, self.norm3.bias, dtype=dtype)
 
     def __call__(self, h, ehs, cak):
-        n = ops.layer_norm(h, self.norm1.weight, self.norm1.bias)
-        h = self.attn1(n, encoder_hidden_states=None, residual=h, **cak)
+        h = self.attn1(h, encoder_hidden_states=None, residual=h, layernorm=(self.norm1, 1e-5), **cak)
         h = self.attn2(h, encoder_hidden_states=ehs, residual=h, layernorm=(self.norm2, 1e-5), **cak)
         B, L, Cc = h.shape
         if self.ff_fused is not None and ops.FUSED_FF and B * L >= ops.FUSED_FF_MIN_ROWS:

@@ -204,7 +204,9 @@ int imd_conv_patch_supported(const imd_conv_gemm_params* p);
 
 /* Row-resident linear layers: K = 320, N = 64..320 in steps of 64 (row_linear.hip, the 64x64-level token matrix; tile config
  * 12 of imd_conv_gemm) and K = 640 / 1280, N a multiple of 160 with a bias / scale / residual / head-split-Q
- * epilogue (row_linear_k640.hip / row_linear_k1280.hip, the 32x32 / 16x16 levels; tile configs 13 / 14).  Same parameter block and fused epilogue as imd_conv_gemm (taps = 1).  Every wave keeps its 32 token rows in registers, the weights stream through LDS by DMA.  ln != 0: LayerNorm
+ * epilogue (row_linear_k640.hip / row_linear_k1280.hip, the 32x32 / 16x16 levels; tile configs 13 / 14); and the fused q / k / v
+ * projection of a 320-channel self-attention layer (K = 320, N = 960, head-split epilogue with Q, K row-major and V transposed,
+ * Hout * Wout a multiple of 128: row_qkv.hip, tile config 15 -- norm1 -> to_q / to_k / to_v as one launch when ln != 0).  Same parameter block and fused epilogue as imd_conv_gemm (taps = 1).  Every wave keeps its 32 token rows in registers, the weights stream through LDS by DMA.  ln != 0: LayerNorm
  * WITHOUT affine (eps = ln_eps) is applied to each row of x on the fly -- BasicTransformerBlock.norm2 -> attn2.to_q as one
  * launch; the caller folds the affine part into the layer: W' = W diag(gamma), b' = b + W beta. */
 int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* stream);

@@ -239,6 +239,42 @@ def test_row_linear_k1280_layernorm_head_split(ops, dt):
     assert_close(q[..., :D], ref, atol=2e-2 if dt == bf16 else None, what="LN + to_q head split k1280")
 
 
+@pytest.mark.parametrize("ln", [False, True])
+@DTS
+def test_row_qkv(ops, ln, dt):
+    """norm1 -> to_q / to_k / to_v of a 320-channel block as ONE launch (row_qkv.hip) == LayerNorm + linear in fp32, in the
+    attention kernel's layouts (Q / K [B, H, N, 48] with Q pre-scaled, V^T [B, H, 64, pad64(N)]); also against the tiled kernel"""
+    B, HW, Cc, H, D = 2, 384, 320, 8, 40
+    DPK, DPV = ops.attn_padded_dims(D)
+    LP = ops.pad64(HW)
+    x = (rnd(1, B * HW, Cc) * 1.4 + 0.5 * rnd(5, 1, Cc)).to(dt); w = rnd(2, 3 * Cc, Cc, scale=Cc ** -0.5).to(dt)
+    g = 1.0 + 0.3 * rnd(6, Cc); be = 0.2 * rnd(7, Cc)
+    def bufs():
+        return (torch.zeros(B, H, HW, DPK, dtype=dt, device="cuda"), torch.zeros(B, H, HW, DPK, dtype=dt, device="cuda"),
+                torch.zeros(B, H, DPV, LP, dtype=dt, device="cuda"))
+    q, k, vt = bufs()
+    heads = dict(C=Cc, H=H, D=D, dests=[(q, 0, DPK, HW, 0.3), (k, 0, DPK, HW, 1.0), (vt, 1, DPV, LP, 1.0)])
+    if ln:
+        w2, b2 = ops.fold_layernorm_affine(dev(w), None, dev(g), dev(be))
+        ops.conv_gemm(dev(x), w2, M=B * HW, N=3 * Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, bias=b2, heads=heads, ln_eps=1e-5)
+        n = F.layer_norm(x.float(), (Cc,), g, be, 1e-5)
+    else:
+        ops.conv_gemm(dev(x), dev(w), M=B * HW, N=3 * Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, heads=heads, cfg=15)
+        n = x.float()
+    ref = F.linear(n, w.float()).view(B, HW, 3, H, D)
+    tol = dict(atol=3e-2 if dt == bf16 else 4e-3)
+    assert_close(q[..., :D], 0.3 * ref[:, :, 0].permute(0, 2, 1, 3), what="Q", **tol)
+    assert_close(k[..., :D], ref[:, :, 1].permute(0, 2, 1, 3), what="K", **tol)
+    assert_close(vt[:, :, :D, :HW], ref[:, :, 2].permute(0, 2, 3, 1), what="V^T", **tol)
+    assert float(q[..., D:].abs().max()) == 0.0 and float(vt[:, :, D:].abs().max()) == 0.0      # padding untouched
+    if not ln:
+        q2, k2, vt2 = bufs()
+        heads2 = dict(C=Cc, H=H, D=D, dests=[(q2, 0, DPK, HW, 0.3), (k2, 0, DPK, HW, 1.0), (vt2, 1, DPV, LP, 1.0)])
+        ops.conv_gemm(dev(x), dev(w), M=B * HW, N=3 * Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, heads=heads2, cfg=4)
+        assert_close(q, q2.float(), atol=1e-2 if dt == bf16 else 2e-3, what="Q vs tiled")
+        assert_close(vt, vt2.float(), atol=2e-2 if dt == bf16 else 4e-3, what="V^T vs tiled")
+
+
 @DTS
 def test_conv_auto_split_small_m(ops, dt):
     """the 8x8 ResNet conv shape (M = 512, K = 11520) takes the automatic split-K path"""
