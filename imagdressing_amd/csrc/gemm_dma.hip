@@ -1,0 +1,171 @@
+// 256 x 256 x 64 tiled GEMM for the large plain linear layers (taps = 1, K % 64 == 0): the GEGLU / feed-forward-out / QKV
+// projections of the 32x32 and 16x16 levels (M = 8192 / 2048 rows, K = 640 ... 5120), which the gather kernel of
+// conv_gemm.hip runs at 450-630 TFLOP/s (matrix pipe ~22 % busy: its operands go global -> VGPR -> ds_write -> barrier ->
+// ds_read every 32- or 64-deep step with two or three small workgroups per CU to hide it).
+//
+// Structure (cdna_hip_programming.md, GEMM staging table: "256^2 tile, ~1 block / CU, LDS-DMA, 2 LDS buffers, BK = 64,
+// vmcnt(0) + plain barrier"):
+//   * one workgroup = 8 waves (4 along M x 2 along N), wave tile 64 x 128 = 8 accumulator blocks: every activation fragment
+//     feeds 4 MFMAs and every weight fragment 2 (0.75 KB of LDS reads per MFMA instead of 1 KB);
+//   * both operand tiles (256 rows x 64 k x 2 B = 32 KB each) go global -> LDS by DMA (buffer_load ... lds) in whole 128-byte
+//     row pieces, double buffered: tile t + 1 is in flight while tile t is multiplied, ONE barrier per 64-deep step; rows
+//     unpadded, piece p of row r stored at p ^ ((r >> 1) & 7) (source-side swizzle) -> conflict-free ds_read_b128;
+//   * out-of-range rows (M / N tails) are out-of-range DMA offsets and arrive as zeros;
+//   * the epilogue is the tiled kernel's: accumulators -> LDS (fp32, 64 rows at a time) -> 8 consecutive channels per thread
+//     through epilogue8 (bias / residual / activations / GEGLU / head-split layouts), XCD-aware tile order.
+// Same arithmetic as conv_gemm.hip (fp32 accumulation over K in 16-element MFMA steps, ascending), same reference layers.
+#include "gemm_common.h"
+#include "lds_dma.h"
+
+namespace {
+
+constexpr int GD_BM = 256, GD_BN = 256, GD_BK = 64;
+constexpr int GD_ROWB = GD_BK * 2;                       // 128 bytes = 8 pieces per operand row and stage
+constexpr int GD_A = GD_BM * GD_ROWB, GD_W = GD_BN * GD_ROWB, GD_STAGE = GD_A + GD_W;     // 32 KB + 32 KB
+constexpr int GD_LDS = 2 * GD_STAGE;                     // 131072
+constexpr int GD_CLD = GD_BN + 4, GD_EROWS = 64;         // fp32 epilogue staging: 64 x 260 x 4 = 66560 bytes
+
+template <bool F16>
+__global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const ConvGemmParams p) {
+    using E = El<F16>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, col = lane & 31;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 128;
+
+    const int n_tiles = (p.N + GD_BN - 1) / GD_BN;
+    int tile_m, tile_n;
+    xcd_tile_order(p.flags, (p.M + GD_BM - 1) / GD_BM, n_tiles, tile_m, tile_n);
+    const int m0 = tile_m * GD_BM, n0 = tile_n * GD_BN;
+    const int nk = p.K / GD_BK;
+
+    // ---- DMA assignments: a stage is 64 pieces of 1 KB (8 rows x 128 B each): pieces 0..31 activations, 32..63 weights ----
+    const v4i_t ds_x = raw_rsrc(p.x, p.x_bytes), ds_w = raw_rsrc(p.w, p.w_bytes);
+    uint32_t soff[8];        // source byte offset of this lane's 16 bytes of piece (j * 8 + wave) at k tile 0, or OOB
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int id = j * 8 + wave;
+        const bool isw = j >= 4;                              // (id >= 32)
+        const int q = (id & 31) * 64 + lane;                 // 16-byte slot inside the operand tile
+        const int row = q >> 3, pos = q & 7;
+        const int pc = pos ^ ((row >> 1) & 7);                // source piece stored at this slot
+        if (isw) soff[j] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + pc * 8) * 2) : OOB;
+        else soff[j] = (m0 + row < p.M) ? (uint32_t)(((size_t)(m0 + row) * p.x_pix_stride + pc * 8) * 2) : OOB;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    auto stage = [&](int kt) {
+        const uint32_t base = lds0 + (uint32_t)((kt & 1) * GD_STAGE);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 8 + wave;
+            dma16(j >= 4 ? ds_w : ds_x, base + (uint32_t)id * 1024u, soff[j] == OOB ? OOB : soff[j] + (uint32_t)(kt * GD_ROWB));
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment addresses: row (wm0 + b * 32 + col) of the activation tile, row (wn0 + a * 32 + col) of the weight tile;
+    // k16 step kk reads piece 2 kk + hi, stored at (2 kk + hi) ^ ((row >> 1) & 7) = (2 kk) ^ (hi ^ f)
+    const uint32_t f16 = (uint32_t)((hi ^ ((col >> 1) & 7)) << 4);       // (row >> 1) & 7 == (col >> 1) & 7: row offsets are multiples of 32
+    const char* xlane = smem + (wm0 + col) * GD_ROWB;
+    const char* wlane = smem + GD_A + (wn0 + col) * GD_ROWB;
+
+    stage(0);
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        dma_wait();                    // this wave's pieces of tile kt have landed
+        __syncthreads();               // ... everybody's; all waves are done with tile kt - 1 (the buffer tile kt + 1 goes to)
+        if (kt + 1 < nk) stage(kt + 1);
+        const char* Xs = xlane + (kt & 1) * GD_STAGE;
+        const char* Ws = wlane + (kt & 1) * GD_STAGE;
+#pragma unroll
+        for (int kk = 0; kk < GD_BK / 16; ++kk) {
+            const uint32_t po = (uint32_t)(kk * 32) ^ f16;
+            uint4 wf[4], xf[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xs + b * 32 * GD_ROWB + po);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + a * 32 * GD_ROWB + po);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
+        }
+    }
+    __syncthreads();                   // the last tile has been read by everybody: LDS becomes the epilogue staging area
+
+    // ---- epilogue (conv_gemm.hip's): one 64-row wave group at a time through LDS (fp32), 8 consecutive channels per thread ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int HWo = p.Hout * p.Wout;
+    constexpr int CPR = GD_BN / 8;                 // 32 chunks per row
+    constexpr int CHUNKS = GD_EROWS * CPR;         // 2048
+    const bool colmajor = p.mode == OUT_HEADS;
+    float4 col_pre0 = make_float4(0, 0, 0, 0), col_pre1 = col_pre0;
+    bool use_col_pre = false;
+    if (!colmajor && (p.bias || p.rowvec)) {       // 512 % 32 == 0: a thread keeps its 8 columns from row to row
+        const int bi_lo = m0 / HWo, bi_hi = (min(m0 + GD_BM, p.M) - 1) / HWo;
+        const int n = n0 + (tid % CPR) * 8;
+        if ((p.rowvec == nullptr || bi_lo == bi_hi) && n < p.N) {
+            load_col_addends(p, p.rowvec ? bi_lo : -1, n, (n + 8 <= p.N) ? 8 : 4, col_pre0, col_pre1);
+            use_col_pre = true;
+        }
+    }
+#pragma unroll 1
+    for (int wr = 0; wr < 4; ++wr) {
+        if ((wave >> 1) == wr) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* dst = Cs + (b * 32 + col) * GD_CLD + wn0 + a * 32 + 8 * j + 4 * hi;
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]);
+                    }
+        }
+        __syncthreads();
+        for (int c = tid; c < CHUNKS; c += 512) {
+            int row, cc;
+            if (colmajor) { cc = (c / GD_EROWS) * 8; row = c - (c / GD_EROWS) * GD_EROWS; }
+            else { row = c / CPR; cc = (c - row * CPR) * 8; }
+            const int m = m0 + wr * GD_EROWS + row, n = n0 + cc;
+            if (m >= p.M || n >= p.N) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * GD_CLD + cc);
+            const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * GD_CLD + cc + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo, use_col_pre, col_pre0, col_pre1);
+        }
+        if (wr + 1 < 4) __syncthreads();
+    }
+}
+
+}  // namespace
+
+bool imd_gemm_dma_supported(const ConvGemmParams& p) {
+    return p.taps == 1 && p.stride == 1 && !p.ups && p.Hin == p.Hout && p.Win == p.Wout && p.Cin == p.K && (p.K % GD_BK) == 0 &&
+           p.split_k <= 1 && p.gn_a == nullptr && (p.x_pix_stride % 8) == 0;
+}
+
+int imd_launch_gemm_dma(const ConvGemmParams& p, hipStream_t s) {      // p: validated and completed (x_bytes, w_bytes, flags) by imd_launch_conv_gemm
+    if (!imd_gemm_dma_supported(p)) return imd_set_error("gemm_dma: needs a plain linear layer with K %% 64 == 0 and no K split (got K=%d taps=%d split=%d)", p.K, p.taps, p.split_k);
+    static bool attr_set[2] = {false, false};
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    const void* kern = h ? reinterpret_cast<const void*>(gemm_dma_kernel<true>) : reinterpret_cast<const void*>(gemm_dma_kernel<false>);
+    if (!attr_set[h]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, GD_LDS);
+        if (e != hipSuccess) return imd_set_error("gemm_dma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set[h] = true;
+    }
+    const long mt = (p.M + GD_BM - 1) / GD_BM, nt = (p.N + GD_BN - 1) / GD_BN;
+    if (h) hipLaunchKernelGGL(gemm_dma_kernel<true>, dim3((unsigned)(mt * nt)), dim3(512), GD_LDS, s, p);
+    else hipLaunchKernelGGL(gemm_dma_kernel<false>, dim3((unsigned)(mt * nt)), dim3(512), GD_LDS, s, p);
+    return imd_check_launch("gemm_dma");
+}

@@ -214,6 +214,8 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg in (12, 13, 14, 15) and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
+            if cfg == 16 and not lib.imd_gemm_dma_supported(C.byref(p)):
+                cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
     if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and not ups and Wout >= PATCH_MIN_W and N >= 64 \

@@ -201,6 +201,8 @@ int imd_groupnorm_workspace_floats(int B, int HW, int C, int G);
 int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* coef_b, void* stream);
 /* 1 iff tile config 5 (LDS-resident halo patch: 3x3, stride 1, H % 8 == 0, W % 16 == 0, Cin % 32 == 0) can run *p. */
 int imd_conv_patch_supported(const imd_conv_gemm_params* p);
+/* 1 iff tile config 16 (256 x 256 x 64 LDS-DMA tile kernel, gemm_dma.hip: plain linear layer, K % 64 == 0, no K split) can run *p. */
+int imd_gemm_dma_supported(const imd_conv_gemm_params* p);
 
 /* Row-resident linear layers: K = 320, N = 64..320 in steps of 64 (row_linear.hip, the 64x64-level token matrix; tile config
  * 12 of imd_conv_gemm) and K = 640 / 1280, N a multiple of 160 with a bias / scale / residual / head-split-Q

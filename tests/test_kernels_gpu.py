@@ -275,6 +275,39 @@ def test_row_qkv(ops, ln, dt):
         assert_close(vt, vt2.float(), atol=2e-2 if dt == bf16 else 4e-3, what="V^T vs tiled")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 320, 320), (1000, 2560, 640), (77, 64, 768), (520, 1284, 1280), (2048 + 19, 520, 128)])
+@DTS
+def test_linear_gemm_dma(ops, M, N, K, dt):
+    """tile config 16: 256 x 256 x 64 tiles staged by LDS-DMA (gemm_dma.hip) == x W^T + b, with the shared epilogues"""
+    x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
+    base = x.float() @ w.float().t() + b
+    assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=16), base, what="gemm_dma")
+    assert_close(ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=16), base + res.float(), what="gemm_dma + residual")
+    if N % 8 == 0:
+        gg = ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_GEGLU, cfg=16)
+        assert_close(gg, base[:, 0::2] * F.gelu(base[:, 1::2]), what="gemm_dma geglu")
+    one = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=16)
+    assert_close(one, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=0).float(), atol=2e-2 if dt == bf16 else 4e-3, what="gemm_dma vs tiled")
+    assert torch.equal(one, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=16)), "not deterministic"
+    with pytest.raises(ops.L.ImdError):
+        ops.linear(dev(rnd(1, 64, 72).to(dt)), dev(rnd(2, 64, 72).to(dt)), cfg=16)           # K % 64 != 0: refused
+
+
+@DTS
+def test_gemm_dma_head_split(ops, dt):
+    """head-split q / k / v epilogue through tile config 16 (the 32x32-level projection: 8 heads x 80)"""
+    B, HW, Cc, H, D = 2, 300, 640, 8, 80
+    DPK, DPV = ops.attn_padded_dims(D); LP = ops.pad64(HW)
+    x = rnd(1, B * HW, Cc).to(dt); w = rnd(2, 3 * Cc, Cc, scale=Cc ** -0.5).to(dt)
+    q = torch.zeros(B, H, HW, DPK, dtype=dt, device="cuda"); k = torch.zeros_like(q); vt = torch.zeros(B, H, DPV, LP, dtype=dt, device="cuda")
+    ops.conv_gemm(dev(x), dev(w), M=B * HW, N=3 * Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, cfg=16,
+                  heads=dict(C=Cc, H=H, D=D, dests=[(q, 0, DPK, HW, 0.3), (k, 0, DPK, HW, 1.0), (vt, 1, DPV, LP, 1.0)]))
+    ref = F.linear(x.float(), w.float()).view(B, HW, 3, H, D)
+    assert_close(q[..., :D], 0.3 * ref[:, :, 0].permute(0, 2, 1, 3), what="Q")
+    assert_close(k[..., :D], ref[:, :, 1].permute(0, 2, 1, 3), what="K")
+    assert_close(vt[:, :, :D, :HW], ref[:, :, 2].permute(0, 2, 3, 1), what="V^T")
+
+
 @DTS
 def test_conv_auto_split_small_m(ops, dt):
     """the 8x8 ResNet conv shape (M = 512, K = 11520) takes the automatic split-K path"""
