@@ -77,8 +77,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 
     const int kt_begin = split * per;
     const int kt_end = min(nk_total, kt_begin + per);
 
+    // staging map.  BK = 32 (80-byte LDS rows, 4 vectors per row): 16 consecutive lanes that write rows R .. R+3 put three of
+    // their sixteen 16-byte pieces on an occupied bank slot (PMC: 30 % of the LDS cycles of the halo-patch kernel were bank
+    // conflicts of exactly this pattern); rows R, R+4, R+8, R+12 do not (5 r mod 16 = 0, 4, 8, 12).
     const int kc = tid % VPR;          // this thread's 16-B column inside a K tile
-    const int r0 = tid / VPR;          // first row it stages
+    const int r0 = (VPR == 4) ? ((tid >> 6) * 16 + ((tid & 63) >> 4) + 4 * ((tid >> 2) & 3)) : tid / VPR;     // first row it stages
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, p.w_bytes, 0x00020000);

@@ -85,8 +85,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     int a_ch[A_VECS];            // channel offset 8*vc (for the fused GroupNorm coefficients)
 #pragma unroll
     for (int i = 0; i < A_VECS; ++i) {
+        // staging map: 16 consecutive lanes write 4 rows x 4 pieces; with the 80-byte row stride rows R, R+1, R+2, R+3 put three
+        // of the sixteen 16-byte pieces on an occupied bank slot, rows R, R+4, R+8, R+12 do not (5 r mod 16 = 0, 4, 8, 12)
         const int v = tid + i * 256;
-        const int pp = v / (CK / 8), vc = v % (CK / 8);
+        const int vq = v & 63, vc = vq & 3;
+        const int pp = (v >> 6) * 16 + (vq >> 4) + 4 * ((vq >> 2) & 3);
         a_lds[i] = -1; a_off[i] = OOB; a_ch[i] = vc * 8;
         if (pp < NPIX) {
             const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
@@ -100,7 +103,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 #pragma unroll
     for (int i = 0; i < W_VECS; ++i) {
         const int v = tid + i * 256;
-        const int row = v / (CK / 8), vc = v % (CK / 8);
+        const int vq = v & 63, vc = vq & 3;
+        const int row = (v >> 6) * 16 + (vq >> 4) + 4 * ((vq >> 2) & 3);      // (same conflict-free staging map)
         w_lds[i] = row * RSTR + vc * 16;
         w_off[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + vc * 8) * 2) : OOB;
     }
