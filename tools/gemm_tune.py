@@ -54,6 +54,46 @@ def time_candidate(t, cfg, split, dt, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+def only_linear(args, shapes, dt):
+    path = os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "gemm_tuning.json")
+    with open(path) as f:
+        doc = json.load(f)
+    table = doc.get("shapes", {})
+    log = []
+    for key, t in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
+        if t["taps"] != 1 or key not in table:
+            continue
+        ent = table[key]
+        shipped = (ent["cfg"], ent["split"]) if t["any_splittable"] else (ent["cfg_nosplit"], 1)
+        cands = {}
+        for rep in range(2):
+            for cand in [shipped] + [(c, 1) for c in (0, 4, 9, 10, 11, 12, 13, 14, 15, 16) if (c, 1) != shipped]:
+                try:
+                    us = time_candidate(t, cand[0], cand[1], dt, args.iters)
+                except Exception:          # noqa
+                    continue
+                cands.setdefault(cand, []).append(us)
+        if shipped not in cands:
+            continue
+        best = min(cands, key=lambda k: min(cands[k]))
+        rec = dict(key=key, count=t["count"], shipped=list(shipped), shipped_us=round(min(cands[shipped]), 1), best=list(best), best_us=round(min(cands[best]), 1))
+        if best != shipped and min(cands[best]) < 0.97 * min(cands[shipped]):
+            if t["any_splittable"]:
+                ent["cfg"], ent["split"] = best
+            if best[1] == 1:
+                ent["cfg_nosplit"] = best[0]
+            rec["changed"] = True
+        log.append(rec)
+        print(json.dumps(rec), flush=True)
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    doc["shapes"] = table
+    with open(args.out, "w") as f:
+        json.dump(doc, f, indent=1)
+    with open(args.out.replace(".json", "_log.jsonl"), "w") as f:
+        for r in log:
+            f.write(json.dumps(r) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=int, default=1, help="BASELINE configuration whose shapes are tuned: 1 (bench line), 3 (IPA + "
@@ -67,9 +107,14 @@ def main():
     ap.add_argument("--out", default="gpurun_out/gemm_tuning.json")
     ap.add_argument("--only-conv3x3", action="store_true",
                     help="re-time only the 3x3 stride-1 convolutions (candidates 0, 4, 5) and merge into the shipped table")
+    ap.add_argument("--only-linear", action="store_true",
+                    help="re-time only the plain linear layers (taps = 1) with the shipped choice against the unsplit candidates 0, 4, 9, 10, 11 and "
+                         "the round-2 kernels 12..16; an entry changes only when the winner is > 3 %% faster than the shipped choice")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     shapes = collect_shapes(args, dt)
+    if args.only_linear:
+        return only_linear(args, shapes, dt)
     result, log = {}, []
     cfgs = CFGS
     splits = [1, 2, 4] if args.quick else SPLITS
