@@ -52,6 +52,7 @@ def parse():
                     help="skip the second timed run in the other 16-bit element type (fp16 when --dtype bf16 and vice versa)")
     ap.add_argument("--attn-qw", type=int, default=0, help="tuning knob 0 of the library (0 = library default)")
     ap.add_argument("--gemm-flags", type=int, default=-1, help="tuning knob 2 of the library (-1 = library default)")
+    ap.add_argument("--splitk-in-kernel", action="store_true", help="A/B: split-K slices summed by each tile's last-arriving workgroup (opt-in, slower)")
     ap.add_argument("--no-fused-ff", action="store_true", help="A/B: norm3 -> GEGLU feed-forward -> + residual of the 64x64 level as four launches")
     ap.add_argument("--no-row-linear", action="store_true",
                     help="A/B: the 64x64-level K = N = 320 projections on the tiled kernel and LayerNorm -> attn2.to_q as two launches")
@@ -223,6 +224,8 @@ def main():
         ops.L.check(ops.L.load().imd_set_tuning(0, args.attn_qw))
     if args.gemm_flags >= 0:
         ops.L.check(ops.L.load().imd_set_tuning(2, args.gemm_flags))
+    if args.splitk_in_kernel:
+        ops.SPLITK_IN_KERNEL = True
     if args.no_fused_ff:
         ops.FUSED_FF = False
     if args.no_row_linear:

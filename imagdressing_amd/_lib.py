@@ -32,6 +32,7 @@ class ConvGemmParams(C.Structure):
         ("hd", HeadsDest * 3), ("dtype", C.c_int), ("split_k", C.c_int), ("splitk_ws", C.c_void_p),
         ("x_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("flags", C.c_int),
         ("gn_a", C.c_void_p), ("gn_b", C.c_void_p), ("gn_silu", C.c_int), ("pad_br_only", C.c_int),
+        ("splitk_counters", C.c_void_p),
     ]
 
 
@@ -130,8 +131,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if lib.imd_abi_version() != 3:
-            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 3")
+        if lib.imd_abi_version() != 4:
+            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 4")
         _lib = lib
     return _lib
 

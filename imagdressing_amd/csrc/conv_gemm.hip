@@ -268,15 +268,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 
             const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc);
             const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * T::CLD + cc + 4);
             if (slab) {                         // raw fp32 partial tile -> slab [split][M][N]
-                float* dst = slab + (size_t)m * p.N + n;
-                *reinterpret_cast<float4*>(dst) = v0;
-                if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
+                slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, p.splitk_counters != nullptr);
             } else {
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo, use_col_pre, col_pre0, col_pre1);
             }
         }
         if (wr + 1 < WAVES_M) __syncthreads();
+    }
+    // K slices summed in-kernel by the tile's last-arriving workgroup (see splitk_last_arrival) instead of by a second launch
+    if (slab != nullptr && p.splitk_counters != nullptr) {
+        if (splitk_last_arrival(p.splitk_counters, tile_m * n_tiles + tile_n, p.split_k, tid)) {
+            for (int c = tid; c < BM * CPR; c += NT) {
+                const int row = c / CPR, cc = (c - row * CPR) * 8;
+                const int m = m0 + row, n = n0 + cc;
+                if (m >= p.M || n >= p.N) continue;
+                const int nv = (n + 8 <= p.N) ? 8 : 4;
+                float v[8];
+                splitk_sum8(p, m, n, nv, v);
+                epilogue8<F16>(p, v, m, n, nv, HWo);
+            }
+        }
     }
 }
 
@@ -319,7 +331,7 @@ int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     const long mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(WM * WN * 64), lds, s, p);
     int rc = imd_check_launch("conv_gemm");
-    if (rc || p.split_k <= 1) return rc;
+    if (rc || p.split_k <= 1 || p.splitk_counters != nullptr) return rc;
     const long chunks = (long)p.M * ((p.N + 7) / 8);
     long blocks = (chunks + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -411,6 +423,14 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         p.flags |= imd_gemm_pick_order(p, (p.N + bn - 1) / bn);
         p.flags |= g_gemm_flags & 16;
     }
+    if (p.split_k <= 1) p.splitk_counters = nullptr;
+    if (p.splitk_counters != nullptr) {          // one counter per output tile; larger grids keep the two-launch path
+        int bm = 128, bn = 128;
+        if (cfg == 5) { bm = 128; bn = 128; } else tile_dims(cfg, &bm, &bn);
+        const long tiles = (cfg == 5) ? (long)(p.M / (p.Hout * p.Wout)) * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16) * ((p.N + 127) / 128)
+                                      : (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+        if (tiles > IMD_SPLITK_COUNTERS || (size_t)p.M * p.N * 4 >= 0x80000000ull) p.splitk_counters = nullptr;
+    }
     if (p.split_k > 1) {
         if (p.mode == OUT_HEADS || p.act == ACT_GEGLU) return imd_set_error("conv_gemm: split-K supports row-major epilogues only");
         if (!p.splitk_ws) return imd_set_error("conv_gemm: split_k = %d needs a workspace", p.split_k);
@@ -433,7 +453,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 11: return h ? launch_cfg<true, 128, 320, 64, 4, 2>(p, s) : launch_cfg<false, 128, 320, 64, 4, 2>(p, s);            // N = 320 k: one full-width row block per CU
         case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
             int rc = imd_launch_conv_patch(p, s);
-            if (rc || p.split_k <= 1) return rc;
+            if (rc || p.split_k <= 1 || p.splitk_counters != nullptr) return rc;
             const long chunks = (long)p.M * ((p.N + 7) / 8);
             long blocks = (chunks + 255) / 256;
             if (blocks > 2048) blocks = 2048;

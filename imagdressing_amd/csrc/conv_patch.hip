@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     const int n_tiles = (p.N + BN - 1) / BN;
     int bid, tile_n;
     xcd_tile_order(p.flags, (int)(gridDim.x / n_tiles), n_tiles, bid, tile_n);      // bid = pixel-tile index
+    const int tile_id = bid * n_tiles + tile_n;
     const int tx = bid % tiles_x; bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
@@ -258,15 +259,29 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
             const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
             const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
             if (slab) {
-                float* dst = slab + (size_t)m * p.N + n;
-                *reinterpret_cast<float4*>(dst) = v0;
-                if (n + 8 <= p.N) *reinterpret_cast<float4*>(dst + 4) = v1;
+                slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, p.splitk_counters != nullptr);
             } else {
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HW, use_col_pre, col_pre0, col_pre1);
             }
         }
         if (wr == 0) __syncthreads();
+    }
+    // K slices summed in-kernel by the tile's last-arriving workgroup (gemm_common.h::splitk_last_arrival)
+    if (slab != nullptr && p.splitk_counters != nullptr) {
+        if (splitk_last_arrival(p.splitk_counters, tile_id, p.split_k, tid)) {
+            for (int ch = tid; ch < TH * TW * CPR; ch += 256) {
+                const int q = ch / CPR, cc = (ch - q * CPR) * 8;
+                const int oy = y0 + q / TW, ox = x0 + q % TW;
+                const int n = n0 + cc;
+                if (n >= p.N || oy >= H || ox >= W) continue;
+                const int m = (b * H + oy) * W + ox;
+                const int nv = (n + 8 <= p.N) ? 8 : 4;
+                float v[8];
+                splitk_sum8(p, m, n, nv, v);
+                epilogue8<F16>(p, v, m, n, nv, HW);
+            }
+        }
     }
 }
 

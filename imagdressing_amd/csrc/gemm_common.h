@@ -157,4 +157,63 @@ __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// split-K without a second launch.  Every workgroup of a K slice writes its fp32 partial tile to its slab; the LAST workgroup
+// to arrive at the tile's counter sums the slabs of the tile in slice order 0 .. S-1 -- the order the finish kernel uses, so
+// the result is bit-identical whoever arrives last -- and runs the epilogue.
+// Coherence: the slices of a tile may run on different XCDs, whose L2s only meet at the memory side.  A release / acquire
+// fence pair at device scope would do (`__threadfence()`), but on this part it writes back and invalidates the WHOLE L2 of the
+// XCD in every workgroup: measured 659 -> 973 ms end to end.  Instead the slab traffic itself is made coherent: partial tiles
+// are stored with sc0 sc1 (write-through to the memory side), the arrival counter is a device-scope atomic issued after the
+// workgroup's stores have been acknowledged (vmcnt(0) + barrier), and the last arrival reads the slabs with sc0 sc1 loads
+// (served from the memory side, never from a stale L1 / L2 line).  Nothing else of the kernel's traffic is touched.
+// ------------------------------------------------------------------------------------------
+constexpr int AUX_SYSTEM = 17;         // buffer cache policy bits sc0 (1) | sc1 (16)
+
+__device__ __forceinline__ void slab_store8(float* slab_base, size_t elem_off, const float4& v0, const float4& v1, bool full, bool coherent) {
+    if (coherent) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab_base, 0, 0x80000000u, 0x00020000);
+        const v4u a = {__float_as_uint(v0.x), __float_as_uint(v0.y), __float_as_uint(v0.z), __float_as_uint(v0.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(a, rs, (int)(elem_off * 4), 0, AUX_SYSTEM);
+        if (full) {
+            const v4u b = {__float_as_uint(v1.x), __float_as_uint(v1.y), __float_as_uint(v1.z), __float_as_uint(v1.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(b, rs, (int)(elem_off * 4 + 16), 0, AUX_SYSTEM);
+        }
+    } else {
+        float* dst = slab_base + elem_off;
+        *reinterpret_cast<float4*>(dst) = v0;
+        if (full) *reinterpret_cast<float4*>(dst + 4) = v1;
+    }
+}
+
+// Returns true in exactly one workgroup per tile; the counter is left at zero for the next launch.
+__device__ __forceinline__ bool splitk_last_arrival(int* counters, int tile_id, int split_k, int tid) {
+    __shared__ int s_ticket;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through slab stores have been acknowledged
+    __syncthreads();                                       // ... everybody's in the workgroup
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(counters + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool last = s_ticket == split_k - 1;
+    if (last && tid == 0) __hip_atomic_store(counters + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return last;
+}
+
+// sum of the K slices of 8 consecutive channels [n, n+8) of row m, in slice order (what splitk_finish_kernel computes), read
+// from the memory side
+__device__ __forceinline__ void splitk_sum8(const ConvGemmParams& p, int m, int n, int nv, float* v) {
+    const size_t slab = (size_t)p.M * p.N;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    const int off = (int)(((size_t)m * p.N + n) * 4);
+    for (int s = 0; s < p.split_k; ++s) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.splitk_ws + s * slab, 0, 0x80000000u, 0x00020000);
+        const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX_SYSTEM);
+        v[0] += __uint_as_float(a[0]); v[1] += __uint_as_float(a[1]); v[2] += __uint_as_float(a[2]); v[3] += __uint_as_float(a[3]);
+        if (nv == 8) {
+            const v4u b = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, AUX_SYSTEM);
+            v[4] += __uint_as_float(b[0]); v[5] += __uint_as_float(b[1]); v[6] += __uint_as_float(b[2]); v[7] += __uint_as_float(b[3]);
+        }
+    }
+}
+
 }  // namespace

@@ -108,6 +108,8 @@ def pad64(n: int) -> int:
 # are not listed fall back to the library heuristic.  Key: "M,N,K,taps,stride,ups".
 PATCH_CONV = True          # untabulated 3x3 stride-1 convs on maps >= PATCH_MIN_W wide use the halo-patch kernel (cfg 5)
 PATCH_MIN_W = 32
+SPLITK_IN_KERNEL = False   # opt-in: K slices summed by each tile's last-arriving workgroup instead of by the finish launch (bit-identical;
+                           # measured SLOWER end to end, 660.5 -> 687.5 ms: the slab traffic must bypass the per-XCD L2s)
 FUSED_FF = True            # engines run norm3 -> GEGLU feed-forward -> + residual of the 320-channel blocks as one launch (ff_fused.hip)
 FUSED_FF_MIN_ROWS = 24576  # below this the 128-row workgroups cannot fill the chip (one per CU at 32768 rows) and the tiled kernels win
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
@@ -226,11 +228,26 @@ def conv_gemm(
     p.split_k = split_k
     if split_k > 1:
         p.splitk_ws = splitk_workspace(split_k * M * N, x.device).data_ptr()
+        if SPLITK_IN_KERNEL:
+            p.splitk_counters = splitk_counters(x.device).data_ptr()
     L.check(lib.imd_conv_gemm(C.byref(p), cfg, _stream()))
     return out
 
 
 _splitk_ws: Dict[str, torch.Tensor] = {}
+
+
+_splitk_cnt: Dict[str, torch.Tensor] = {}
+
+
+def splitk_counters(device) -> torch.Tensor:
+    """Zeroed per-tile arrival counters of the in-kernel split-K reduction (include/imagdressing_hip.h::splitk_counters); every
+    launch leaves them zero, launches are stream-ordered, so one array per device serves all of them."""
+    t = _splitk_cnt.get(str(device))
+    if t is None:
+        t = torch.zeros(16384, dtype=torch.int32, device=device)
+        _splitk_cnt[str(device)] = t
+    return t
 
 
 def splitk_workspace(nfloats: int, device) -> torch.Tensor:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 3
+#define IMD_ABI_VERSION 4
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -71,7 +71,11 @@ typedef struct imd_conv_gemm_params {
     int gn_silu;
     int pad_br_only;     /* 3x3 taps: 0 = symmetric zero padding 1 (UNet); 1 = padding on the bottom / right edge only, i.e.
                           * F.pad(x, (0, 1, 0, 1)) + conv(padding = 0): the stride-2 Downsample2D of the VAE encoder */
+    int* splitk_counters; /* split_k > 1 only.  NULL: the K slices are summed by a second launch (fixed order).  Otherwise >=
+                          * IMD_SPLITK_COUNTERS ints that are ZERO on entry and are left zero: every output tile's last-arriving
+                          * workgroup sums the slices itself, in the same fixed order (bit-identical results, one launch less) */
 } imd_conv_gemm_params;
+#define IMD_SPLITK_COUNTERS 16384
 
 typedef struct imd_attn_params {
     const uint16_t* q;   /* [B, H, N, DPK], pre-scaled by D^-1/2 * log2(e) */

@@ -93,6 +93,15 @@ def test_linear_split_k(ops, M, N, K, split, cfg, dt):
     one = ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=1)
     assert_close(out, one.float(), atol=2e-2 if dt == bf16 else 4e-3, what="split vs unsplit")
     assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=split)), "not deterministic"
+    # the in-kernel reduction (last-arriving workgroup of every tile) and the separate finish launch sum in the same order
+    ops.SPLITK_IN_KERNEL = True
+    try:
+        fused = ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=split)
+        fused2 = ops.linear(dev(x), dev(w), dev(b), res=dev(res), act=ops.ACT_SILU, cfg=cfg, split_k=split)
+    finally:
+        ops.SPLITK_IN_KERNEL = False
+    assert torch.equal(out, fused) and torch.equal(out, fused2), "in-kernel split-K reduction differs from the finish kernel"
+    assert int(ops.splitk_counters(out.device).abs().max()) == 0, "arrival counters not left at zero"
 
 
 @pytest.mark.parametrize("M,N", [(128, 320), (300, 320), (4096 + 37, 320), (200, 64), (1000, 192), (129, 256)])
@@ -367,6 +376,15 @@ def test_conv3x3_halo_patch(ops, B, H, W, Cin, Cout, split, dt):
     out = ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), rowvec=dev(temb), rowvec_stride=Cout,
                           res=dev(res), cfg=5, split_k=split)
     assert_close(out, ref, what=f"halo-patch conv split={split}")
+    if split > 1:        # in-kernel reduction by the last-arriving workgroup == separate finish launch, bit for bit; counters left at zero
+        ops.SPLITK_IN_KERNEL = True
+        try:
+            two = ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), rowvec=dev(temb), rowvec_stride=Cout,
+                                  res=dev(res), cfg=5, split_k=split)
+        finally:
+            ops.SPLITK_IN_KERNEL = False
+        assert torch.equal(out, two)
+        assert int(ops.splitk_counters(out.device).abs().max()) == 0
     with pytest.raises(ops.L.ImdError):
         ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), stride=2, cfg=5)
 
