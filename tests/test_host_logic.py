@@ -331,3 +331,55 @@ def test_unipc_coefficient_lists_equal_the_library_form_oracle():
                 if sch.lower_order_nums < order:
                     sch.lower_order_nums += 1
                 assert np.allclose(x, xo.numpy(), rtol=1e-9, atol=1e-10), (order, N, pos, np.abs(x - xo.numpy()).max())
+
+
+def test_pack_ff_fused_is_an_exact_reparametrisation():
+    """ops.pack_ff_fused (operands of the one-launch feed-forward, csrc/ff_fused.hip): emulate on the CPU what the kernel does with
+    the packed tensors -- first GEMM in packed row order, value / gate pairing by accumulator register (rows i and i + 8), the
+    lane's GEGLU outputs taken in register order as the k-slots of the packed second GEMM -- and compare with
+    LayerNorm -> Linear -> GEGLU -> Linear + residual on the original parameters."""
+    import torch.nn.functional as F
+    from imagdressing_amd import ops
+    g = torch.Generator().manual_seed(0)
+    Cc, inner, M = 320, 1280, 6
+    x = torch.randn(M, Cc, generator=g, dtype=torch.float64)
+    w1 = torch.randn(2 * inner, Cc, generator=g, dtype=torch.float64) * Cc ** -0.5; b1 = torch.randn(2 * inner, generator=g, dtype=torch.float64)
+    w2 = torch.randn(Cc, inner, generator=g, dtype=torch.float64) * inner ** -0.5; b2 = torch.randn(Cc, generator=g, dtype=torch.float64)
+    gam = 1 + 0.3 * torch.randn(Cc, generator=g, dtype=torch.float64); bet = 0.2 * torch.randn(Cc, generator=g, dtype=torch.float64)
+    pk = ops.pack_ff_fused(w1, b1, w2, b2, gam, bet, dtype=torch.float64)
+    assert pk["w1"].shape == (2 * inner, Cc) and pk["b1"].shape == (2 * inner,) and pk["w2"].shape == (inner // 32, Cc, 32) and pk["ln"]
+    n = F.layer_norm(x, (Cc,), None, None, 1e-5)                      # the kernel normalises WITHOUT affine
+    out = x + b2
+    for blk in range(inner // 16):                                    # one 32-row MFMA block of the first GEMM = 16 inner channels
+        acc = n @ pk["w1"][32 * blk:32 * blk + 32].t() + pk["b1"][32 * blk:32 * blk + 32]          # [M, 32 packed rows]
+        h = torch.empty(M, 16, dtype=torch.float64)                   # k-slot order of the second GEMM
+        for hi in range(2):                                           # lane half: accumulator register r <-> packed row (r & 3) + 8 (r >> 2) + 4 hi
+            row = lambda r: (r & 3) + 8 * (r >> 2) + 4 * hi
+            for e in range(4):
+                h[:, 8 * hi + e] = acc[:, row(e)] * F.gelu(acc[:, row(4 + e)])
+                h[:, 8 * hi + 4 + e] = acc[:, row(8 + e)] * F.gelu(acc[:, row(12 + e)])
+        c, t = blk // 2, blk % 2
+        out = out + h @ pk["w2"][c][:, 16 * t:16 * t + 16].t()
+    hid, gate = F.linear(F.layer_norm(x, (Cc,), gam, bet, 1e-5), w1, b1).chunk(2, dim=-1)
+    ref = x + F.linear(hid * F.gelu(gate), w2, b2)
+    assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5), float((out - ref).abs().max())      # (the packer folds in fp32)
+
+
+def test_tuning_table_only_names_known_tile_configs():
+    import json
+    import os
+    from imagdressing_amd import ops
+    with open(os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "gemm_tuning.json")) as f:
+        shapes = json.load(f)["shapes"]
+    assert len(shapes) > 250
+    for key, ent in shapes.items():
+        M, N, K, taps, stride, ups = map(int, key.split(","))
+        for c in (ent["cfg"], ent["cfg_nosplit"]):
+            assert c in range(0, 17), (key, ent)
+            if c == 12: assert K == 320 and N <= 320 and N % 64 == 0 and taps == 1, key
+            if c == 13: assert K == 640 and N % 160 == 0 and taps == 1, key
+            if c == 14: assert K == 1280 and N % 160 == 0 and taps == 1, key
+            if c == 15: assert K == 320 and N == 960 and taps == 1, key
+            if c == 16: assert K % 64 == 0 and taps == 1, key
+            if c == 5: assert taps == 9 and stride == 1 and not ups, key
+        assert ent["split"] >= 1 and (ent["split"] == 1 or ent["cfg"] not in (12, 13, 14, 15, 16)), (key, ent)
