@@ -129,13 +129,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 
     // re-read (shifted by one pixel) the activation lines the previous tile just pulled into the L1.
     const bool tap_inner = (p.flags & 1) != 0;
     const bool w_bypass_l1 = (p.flags & 2) != 0;
+    // tap of a k index without an integer division by the runtime Cin (~35 VALU instructions per K tile and wave, 40 % of the
+    // kernel's VALU work on the 8x8 / 16x16 maps where a wave has only 4 MFMAs per tile): (k + 0.5) / Cin is at least 0.5 / Cin
+    // away from an integer, far more than fp32 rounding for k < 2^24
+    const float inv_cin = 1.0f / (float)p.Cin;
     auto load_tile = [&](int kt, uint4 (&a_reg)[A_VECS], uint4 (&w_reg)[W_VECS]) {
         int kbase = kt * BK;
-        if (tap_inner) { const int c = kt / 9; kbase = (kt - 9 * c) * p.Cin + c * BK; }
+        int tap = 0, ci = 0;
+        if (tap_inner) {                  // (Cin % BK == 0: a tile never straddles two taps)
+            const int c = kt / 9;
+            tap = kt - 9 * c; ci = c * BK + kc * 8;
+            kbase = tap * p.Cin + c * BK;
+        }
         const int k = kbase + kc * 8;
         const bool kv = (k < p.K) && (kt < nk_total);
-        int tap = 0, ci = k;
-        if (p.taps == 9) { tap = k / p.Cin; ci = k - tap * p.Cin; }
+        if (!tap_inner) {
+            ci = k;
+            if (p.taps == 9) { tap = (int)(((float)k + 0.5f) * inv_cin); ci = k - tap * p.Cin; }
+        }
         const int ky = tap / 3, kx = tap - ky * 3;
         const int tap_delta = (ky * p.Win + kx) * p.x_pix_stride + ci;     // same for every row of the tile
 #pragma unroll
