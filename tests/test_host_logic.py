@@ -2,6 +2,7 @@
 import os
 
 import pytest
+from types import SimpleNamespace
 import torch
 
 from imagdressing_amd import dist as D
@@ -383,3 +384,62 @@ def test_tuning_table_only_names_known_tile_configs():
             if c == 16: assert K % 64 == 0 and taps == 1, key
             if c == 5: assert taps == 9 and stride == 1 and not ups, key
         assert ent["split"] >= 1 and (ent["split"] == 1 or ent["cfg"] not in (12, 13, 14, 15, 16)), (key, ent)
+
+
+def test_fold_layernorm_affine_is_exact_algebra():
+    """LN_affine(x) W^T + b == LN_plain(x) W'^T + b' with (W', b') = ops.fold_layernorm_affine (the host side of the fused
+    LayerNorm -> linear launches)"""
+    import torch.nn.functional as F
+    from imagdressing_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(7, 320, generator=g, dtype=torch.float64) * 2 + 0.3
+    w = torch.randn(96, 320, generator=g, dtype=torch.float64); b = torch.randn(96, generator=g, dtype=torch.float64)
+    gam = 1 + 0.4 * torch.randn(320, generator=g, dtype=torch.float64); bet = 0.3 * torch.randn(320, generator=g, dtype=torch.float64)
+    w2, b2 = ops.fold_layernorm_affine(w, b, gam, bet)
+    ref = F.linear(F.layer_norm(x, (320,), gam, bet, 1e-5), w, b)
+    got = F.linear(F.layer_norm(x, (320,), None, None, 1e-5), w2.double(), b2.double())
+    assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5), float((got - ref).abs().max())      # (the fold itself runs in fp32)
+    w3, b3 = ops.fold_layernorm_affine(w, None, gam, bet)
+    assert torch.allclose(b3.double(), w @ bet, atol=1e-5)
+
+
+def test_engine_attention_hands_unnormalised_states_only_to_processors_that_opted_in(monkeypatch):
+    """unet.Attention.__call__(layernorm=...): processors of this package that declare ``fused_layernorm`` (and ``fused_residual``)
+    receive the block's raw hidden state plus ``imd_layernorm``; every other processor -- the diffusers protocol -- receives
+    normalised states and never sees the extra keyword."""
+    from imagdressing_amd import ops, unet
+    calls = []
+    monkeypatch.setattr(ops, "layer_norm", lambda x, w, b, eps=1e-5, out=None: (calls.append("ln"), x + 1000.0)[1])
+    monkeypatch.setattr(ops, "add", lambda a, b, *args, **kw: a + b)
+    norm = SimpleNamespace(weight=torch.ones(320), bias=torch.zeros(320))
+
+    class Foreign:                       # a diffusers-style processor: positional protocol, no opt-in attributes
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, **kw):
+            assert "imd_layernorm" not in kw and "imd_residual" not in kw
+            self.seen = hidden_states
+            return hidden_states
+
+    class Engine:
+        fused_residual = True
+        fused_layernorm = True
+
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, imd_residual=None, imd_layernorm=None, **kw):
+            self.seen, self.ln = hidden_states, imd_layernorm
+            return hidden_states
+
+    a = unet.Attention.__new__(unet.Attention)
+    a.dtype = torch.float32
+    h = torch.zeros(2, 128, 320); ehs = torch.zeros(2, 77, 768)
+    a.processor = Foreign()
+    a(h, encoder_hidden_states=ehs, residual=h, layernorm=(norm, 1e-5))
+    assert calls == ["ln"] and float(a.processor.seen.min()) == 1000.0           # normalised by the engine, in front of the processor
+    calls.clear()
+    a.processor = Engine()
+    a(h, encoder_hidden_states=ehs, residual=h, layernorm=(norm, 1e-5))
+    assert calls == [] and float(a.processor.seen.max()) == 0.0 and a.processor.ln[2] == 1e-5       # raw state + the norm's parameters
+    a(torch.zeros(2, 128, 96), encoder_hidden_states=ehs, residual=None, layernorm=(norm, 1e-5))     # a width no fused kernel exists for
+    assert calls == ["ln"] and a.processor.ln is None
+    calls.clear()
+    monkeypatch.setattr(ops, "FUSED_LN", False)                                 # the A/B switch restores the two-launch path
+    a(h, encoder_hidden_states=ehs, residual=h, layernorm=(norm, 1e-5))
+    assert calls == ["ln"] and a.processor.ln is None
