@@ -199,7 +199,8 @@ def _project_kv(tokens: torch.Tensor, wkv: torch.Tensor, heads: int):
     return k, vt, Lk, LP
 
 
-_FP8_KV: Dict[int, tuple] = {}
+_FP8_KV: Dict[int, tuple] = {}          # (dropped by ops.clear_workspaces(): it pins the 16-bit K and the e4m3 K / V^T of every layer)
+ops._clear_hooks.append(_FP8_KV.clear)
 
 
 def _fp8_kv(kv, cache: bool):
@@ -281,9 +282,11 @@ class _FusedBase:
         return B // Be
 
     @staticmethod
-    def _finish(attn, out, residual_given, like, shape4):
+    def _finish(attn, out, residual_given, like, shape4, ln_fused=False):
         # attn.residual_connection / rescale_output_factor are False / 1.0 for SD1.5 (:622-625)
         if getattr(attn, "residual_connection", False) and not residual_given:
+            if ln_fused:       # `like` is then the block's UN-normalised state, not this layer's input: the add would be wrong
+                raise NotImplementedError("attn.residual_connection together with the engine's fused LayerNorm (imd_layernorm)")
             out = ops.add(out, _as_tokens(like, out.dtype)[0])
         if getattr(attn, "rescale_output_factor", 1.0) != 1.0:
             raise NotImplementedError("rescale_output_factor != 1 is not used by SD1.5")
@@ -333,7 +336,7 @@ class AttnProcessor2_0(_FusedBase):
             out = _fused_attention(x, attn.heads, wq_or_qkv=_layer_weights(attn, "q", dt, dev), self_attn=False, kv1=kv,
                                    kv1_bdiv=self._ehs_bdiv(x.shape[0], encoder_hidden_states), wo=wo, bo=bo,
                                    residual=imd_residual, q_ln=q_ln)
-        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
+        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4, ln_fused=imd_layernorm is not None)
 
 
 class CacheAttnProcessor2_0(AttnProcessor2_0):
@@ -440,7 +443,7 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
             s2 = self._branch_weights(x.shape[0], sa_batch_mask, x.device)
         out = _fused_attention(x, attn.heads, wq_or_qkv=wqkv, self_attn=True, kv2=kv2, kv2_bdiv=bdiv2,
                                scale2=s2, wo=wo, bo=bo, residual=imd_residual, q_ln=q_ln)
-        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
+        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4, ln_fused=imd_layernorm is not None)
 
 
 class _LoraFold:

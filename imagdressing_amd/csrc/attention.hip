@@ -443,15 +443,17 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 // head-dim-40 kernel variant (tuning knob 0, imd_set_tuning(0, v)); all variants give the same result up to fp32 order:
-//   9 (default): attention_d40.hip, software-pipelined steps with the MFMA / VALU interleave written out (N >= 512; shorter
-//      sequences and the causal mask fall through to variant 4 below), K / V^T staged by LDS-DMA when the caller guarantees
-//      K's pad column (imd_attn_params.k_pad_one), through registers otherwise;  7: always through registers;
-//      6: as 7 without the pinned interleave;  8: as 7 with the deferred-maximum bound 2^12;  10..15: timing ablations
+//   10 (default): attention_d40.hip, software-pipelined steps with the MFMA / VALU interleave written out (N >= 512; shorter
+//      sequences and the causal mask fall through to variant 4 below), head-dim rows 32..40 of P.V on v_mfma_f32_16x16x32,
+//      K / V^T staged by LDS-DMA when the caller guarantees K's pad column (imd_attn_params.k_pad_one), through registers
+//      otherwise;  11: as 10, always through registers;  9 / 7: the round-2 kernel (P.V as two 32x32x16 row blocks) with the
+//      same two staging rules;  6: as 7 without the pinned interleave;  8: as 7 with the deferred-maximum bound 2^12;
+//      20..39: timing ablations, -DIMD_ABLATIONS builds only
 //   5: as 2 with the next tile's loads issued unconditionally (+7 % over 2)
 //   2: 2 query blocks per wave, 32-key softmax blocks, speculative exp (round-1 default)
 //   4: 1 query block per wave, 32-key blocks, speculative exp      3: 1 query block, 64-key blocks, exact max every block
 //   1: as 3 with speculative exp
-int g_attn_qw40 = 9;
+int g_attn_qw40 = 10;
 
 int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }

@@ -39,6 +39,7 @@ constexpr int VROWS = D + 1;                // 40 head-dim rows + the all-ones r
 constexpr int VBYTES = VROWS * VSTR;        // rows 41..63 of the second 32-row MFMA block are NOT stored: their fragment
 constexpr int BUF = VBYTES + KT * KSTR;     // reads run into the K rows behind (finite garbage into accumulator rows nobody reads)
 constexpr int PARK = 4 * 5 * 1024;          // phase-0 result: 4 waves x 20 packed dwords per lane
+constexpr int PARK_T = 4 * 6 * 1024;        // ... x 24 packed dwords per lane with the 16x16x32 tail (VAR & 8192)
 static_assert((DPV - VROWS) * VSTR <= KT * KSTR, "phantom V^T rows must stay inside the K rows");
 // LDS-DMA staging (VAR & 128): `buffer_load ... lds` writes lane-linear (wave-uniform base + lane * 16 B), so rows cannot be
 // padded; bank conflicts are avoided by choosing WHICH 16-byte piece of global memory a lane fetches instead:
@@ -48,7 +49,7 @@ static_assert((DPV - VROWS) * VSTR <= KT * KSTR, "phantom V^T rows must stay ins
 constexpr int KSTR_D = DPK * 2, VSTR_D = KT * 2, VBYTES_D = VROWS * VSTR_D, BUF_D = VBYTES_D + KT * KSTR_D;
 constexpr int NRING = 3;                    // LDS-DMA ring: unit u + 2 is in flight while unit u is consumed (an L2 miss served by the
                                             // Infinity Cache takes about as long as one iteration: one unit of lead was not enough)
-constexpr int LDS_BYTES_D = NRING * BUF_D + PARK + 1024;      // + 1 KB dump for the fourth wave's third (empty) DMA piece
+// LDS per workgroup (LDS-DMA variants): NRING * BUF_D + park + 1 KB dump for the fourth wave's third (empty) DMA piece
 static_assert((DPV - VROWS) * VSTR_D <= KT * KSTR_D, "phantom V^T rows must stay inside the K rows");
 
 typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u;
@@ -67,6 +68,13 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
 }
 
 // VAR bit 0: MFMA / VALU interleave written out and pinned   bit 1: plain (not XCD-aware) work order
+//   8192 (TAIL): head-dim rows 32..40 of O^T += V^T P^T (+ the all-ones row 40 that yields the softmax denominator) on
+//   v_mfma_f32_16x16x32 instead of a second 32x32x16 row block: 16 padded rows instead of 32, i.e. 6 instead of 7
+//   MFMA-equivalents per query block and 32-key step (issued / algorithmic matrix work 1.41 -> 1.21).  The packed P registers
+//   of a 32x32 S^T tile hold one query per LANE COLUMN (l & 31); the 16x16x32 B operand wants one query per l & 15 with the
+//   four 16-lane rows carrying four 8-key slot groups: ONE v_permlane16_swap_b32 per register pair (g = 0 word, g = 1 word)
+//   turns them into the operands of the two 16-query halves (lane row k then carries keys {0..7, 16..23, 8..15, 24..31}[k]
+//   of the step; the V^T fragment is read in the same slot order).  Accumulators: 2 x (16 + 2 x 4) instead of 2 x 32.
 // ABLATION bits (timing experiments only, results are WRONG): 4: exp2 replaced by a move   8: no barrier in the loop
 //   16: no global loads / LDS stores in the loop   32: no P.V MFMAs   64: no QK^T MFMAs   256: one LDS fragment read per step
 //   512: 100 KB of LDS per workgroup (one workgroup = one wave per SIMD)   2048: no packed-max / overflow test
@@ -75,6 +83,8 @@ template <bool F16, int THR, int VAR>
 __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
     using E = El<F16>;
     constexpr bool DMA = (VAR & 128) != 0;
+    constexpr bool TAIL = (VAR & 8192) != 0;
+    constexpr int PARKB = TAIL ? PARK_T : PARK;
     constexpr int BUFB = DMA ? BUF_D : BUF, VBY = DMA ? VBYTES_D : VBYTES;
     constexpr float OFFS_THR = (float)THR;                 // deferred maximum: P <= 2^THR (base-2 units)
     constexpr int QPAD_T = D / 16, QPAD_HI = (D % 16) / 8;  // Q fragment / half-wave holding pad slot 40 (element 0 of the fragment)
@@ -139,18 +149,33 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) vfd[g] = col * VSTR_D + (((2 * g + hi) ^ sw) * 16);
     }
-    char* park = smem + (DMA ? NRING : 2) * BUFB + wave * 5120 + lane * 16;
+    // TAIL: V^T rows 32..47 x the step's 32 keys as the A operand of v_mfma_f32_16x16x32: lane l = row 32 + (l & 15), slot
+    // group l >> 4 = keys {0, 16, 8, 24}[l >> 4] + 0..7 (the order the permlane16-swapped P registers carry).  DMA layout:
+    // piece c of row 32 + r sits at position c ^ tail_sw(r) (source-side swizzle chosen for THIS read: the 16 lanes of a
+    // ds_read_b128 group cover all 16 rows, eight of them at piece p and eight at piece p ^ 2 -> 16 distinct bank slots)
+    int tfd[2];
+    {
+        const int r = lane & 15, kq = lane >> 4, pc0 = ((kq & 1) << 1) | (kq >> 1);
+        const int tsw = ((r >> 1) & 7) ^ ((r >= 4 && r < 12) ? 2 : 0);
+#pragma unroll
+        for (int sec = 0; sec < 2; ++sec)
+            tfd[sec] = DMA ? (32 + r) * VSTR_D + (((4 * sec + pc0) ^ tsw) * 16) : (32 + r) * VSTR + (4 * sec + pc0) * 16;
+    }
+    char* park = smem + (DMA ? NRING : 2) * BUFB + wave * (PARKB / 4) + lane * 16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     unsigned long long tm_slots = 0, tm_check = 0, tm_sync = 0, tm_loop = 0, tm_steps = 0;      // VAR & 4096 only
     for (int ph = 0; ph < nph; ++ph) {
         f32x16 o[2][2];
+        f32x4 ot[2][2];                 // TAIL: rows 32..47 of O^T, [query block][16-query half]; o[.][1] is unused then
         float m_ref[2] = {0.f, 0.f};
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             if (hi == QPAD_HI) qf[qb][QPAD_T].x &= 0xffff0000u;       // Q pad slot = -m_ref = 0
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) o[qb][dt] = zero16;
+            ot[qb][0] = zero4; ot[qb][1] = zero4;
         }
         const int L = ph ? p.L2 : p.L1;
         const int LP = ph ? p.L2P : p.L1P;
@@ -204,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                 dsrc[i] = (32 + r) * (DPK * 2) + c * 16;
                 dneg[i] = r < 32;                                // unit -1: rows 64 u + 32 + r = r - 32
             } else {
-                const int sl = 64 * (qi - 6) + lane, dd = sl >> 3, ch = (sl & 7) ^ ((dd >> 1) & 7);
+                const int sl = 64 * (qi - 6) + lane, dd = sl >> 3, rt = dd - 32;
+                const int sw = (TAIL && dd >= 32) ? (((rt >> 1) & 7) ^ ((rt >= 4 && rt < 12) ? 2 : 0)) : ((dd >> 1) & 7);
+                const int ch = (sl & 7) ^ sw;
                 dsrc[i] = (dd * LP + ch * 8 - 32) * 2;
                 dneg[i] = ch < 4;                                // unit 0: columns ch * 8 - 32 .. < 0
             }
@@ -216,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                 const bool isk = qi < 6, none = qi >= 11;
                 const bool bad = none || (isk ? (u < 0 && dneg[i]) : (u <= 0 && (u < 0 || dneg[i])));
                 const uint32_t off = bad ? OOB : (uint32_t)(dsrc[i] + u * (isk ? KT * DPK * 2 : KT * 2));
-                const uint32_t dst = none ? smem_base + NRING * BUF_D + PARK
+                const uint32_t dst = none ? smem_base + NRING * BUF_D + PARKB
                                           : smem_base + bufi * BUF_D + (isk ? VBYTES_D + 1024 * qi : 1024 * (qi - 6));
                 dma16(isk ? ds_k : ds_v, dst, off);
             }
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         // after the other and hipcc's scheduler decides.
         uint4 fr[3];                 // LDS fragment ring: fragment f of a step lives in fr[(R0 + f) % 3]
         auto step = [&](const char* Vs, auto second_c, int j, f32x16 (&sc)[2], f32x16 (&sn)[2], uint4 (&pc)[2][2],
-                        const uint4 (&pp)[2][2]) {
+                        uint4 (&pp)[2][2]) {
             constexpr bool SECOND = decltype(second_c)::value;        // second step of a unit: K block kb = 1, V^T groups 2, 3
             constexpr int KB = SECOND ? 1 : 0, G0 = SECOND ? 2 : 0, R0 = SECOND ? 1 : 0;
             const char* Ks = Vs + VBY;
@@ -269,7 +296,57 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                 word(pr) = E::pack2(sc[qb][r0], sc[qb][r0 + 1]);
             };
             uint32_t mq[2] = {0u, 0u};
-            if (VAR & 1) {
+            if constexpr (TAIL) {
+                // fragment sequence of a step: 0, 1 = V^T rows 0..31 x key groups G0, G0 + 1;  2..4 = K chunks 0..2;  5 = V^T tail.
+                // MFMA slots: 0..3 O^T(rows 0..31) += V^T P^T (the previous block's P in its 32x32 layout), 4..9 S_n = K Q^T,
+                // 10..13 the four 16x16x32 tail MFMAs (query block, 16-query half) on P swapped in place during slots 4..11.
+                auto fragT = [&](int sq, int sec) -> uint4 {
+                    const int g0 = sec ? 2 : 0;
+                    if (sq < 2) return DMA ? *reinterpret_cast<const uint4*>(Vs + vfd[g0 + sq])
+                                           : *reinterpret_cast<const uint4*>(Vs + vfrag + (g0 + sq) * 32);
+                    if (sq < 5) return DMA ? *reinterpret_cast<const uint4*>(Ks + sec * 32 * KSTR_D + kfd[sq - 2])
+                                           : *reinterpret_cast<const uint4*>(Ks + sec * 32 * KSTR + kfrag + (sq - 2) * 32);
+                    return *reinterpret_cast<const uint4*>(Vs + tfd[sec]);
+                };
+                auto mmaT = [&](int i) {
+                    const uint4& fa = fr[(i < 10 ? (i >> 1) : 5) % 3];
+                    if (i < 4) o[i & 1][0] = E::mfma(fa, pp[i & 1][i >> 1], o[i & 1][0]);
+                    else if (i < 10) sn[i & 1] = E::mfma(fa, qf[i & 1][(i >> 1) - 2], i < 6 ? zero16 : sn[i & 1]);
+                    else ot[(i - 10) >> 1][i & 1] = E::mfma16(fa, pp[(i - 10) >> 1][i & 1], ot[(i - 10) >> 1][i & 1]);
+                };
+                auto swapT = [&](int k) {        // word k & 3 of query block k >> 2: (g = 0, g = 1) -> (queries 0..15, queries 16..31)
+                    uint4& a = pp[k >> 2][0];
+                    uint4& b = pp[k >> 2][1];
+                    uint32_t& x = (k & 3) == 0 ? a.x : (k & 3) == 1 ? a.y : (k & 3) == 2 ? a.z : a.w;
+                    uint32_t& y = (k & 3) == 0 ? b.x : (k & 3) == 1 ? b.y : (k & 3) == 2 ? b.z : b.w;
+                    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+                    x = r[0]; y = r[1];
+                };
+                if (!SECOND) {       // (the second step's first two fragments were read during the first step's last slots)
+                    fr[0] = fragT(0, 0);
+                    fr[1] = fragT(1, 0);
+                }
+                exp_pair(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 14; ++i) {
+                    if ((i & 1) == 0) {
+                        const int f2 = (i >> 1) + 2;
+                        if (f2 <= 5) fr[f2 % 3] = fragT(f2, SECOND ? 1 : 0);
+                        else if (!SECOND && f2 <= 7) fr[f2 - 6] = fragT(f2 - 6, 1);     // next step's fragments 0 and 1 (slots 8, 10)
+                    }
+                    mmaT(i);
+                    exp_pair(i + 1);
+                    cvt_pair(i);
+                    if (i & 1) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
+                    if (i >= 4 && i < 12) swapT(i - 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                exp_pair(15);
+                cvt_pair(14);
+                cvt_pair(15);
+                mq[0] = pk_max3(mq[0], word(14), word(15));
+            } else if (VAR & 1) {
                 if (!SECOND) {       // (the second step's first two fragments were read during the first step's last slots)
                     fr[0] = frag(0, KB, G0);
                     fr[1] = frag(1, KB, G0);
@@ -343,9 +420,17 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                         if (!first) {       // on the first block O is still 0 (and delta may be hugely negative: 2^-delta = inf)
                             const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-                            for (int dt = 0; dt < 2; ++dt)
+                            for (int dt = 0; dt < (TAIL ? 1 : 2); ++dt)
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) o[qb][dt][r] *= alpha;
+                            if constexpr (TAIL) {       // tail accumulators: lane l holds query 16 hq + (l & 15) of the block
+#pragma unroll
+                                for (int hq = 0; hq < 2; ++hq) {
+                                    const float at = __shfl(alpha, (lane & 15) + 16 * hq);
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) ot[qb][hq][r] *= at;
+                                }
+                            }
                         }
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { sc[qb][r] -= delta; sn[qb][r] -= delta; }
@@ -417,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         if (VAR & 4096) tm_loop += __builtin_amdgcn_s_memtime() - t_loop0;
         if (DMA) {
             const char* Vs = smem + ring * BUFB;                     // unit NUF
-            auto drain = [&](int g0, const uint4 (&pp)[2][2]) {      // O += V^T P^T of the last block; nothing left to score
+            auto drain = [&](int g0, uint4 (&pp)[2][2]) {      // O += V^T P^T of the last block; nothing left to score
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < (TAIL ? 1 : 2); ++dt)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         const uint4 vf = DMA ? *reinterpret_cast<const uint4*>(Vs + dt * 32 * VSTR_D + vfd[g0 + g])
@@ -427,6 +512,21 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
 #pragma unroll
                         for (int qb = 0; qb < 2; ++qb) o[qb][dt] = E::mfma(vf, pp[qb][g], o[qb][dt]);
                     }
+                if constexpr (TAIL) {
+                    const uint4 tf = *reinterpret_cast<const uint4*>(Vs + tfd[g0 >> 1]);
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) {
+                        uint32_t* a = reinterpret_cast<uint32_t*>(&pp[qb][0]);
+                        uint32_t* b = reinterpret_cast<uint32_t*>(&pp[qb][1]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const auto r = __builtin_amdgcn_permlane16_swap(a[c], b[c], false, false);
+                            a[c] = r[0]; b[c] = r[1];
+                        }
+#pragma unroll
+                        for (int hq = 0; hq < 2; ++hq) ot[qb][hq] = E::mfma16(tf, pp[qb][hq], ot[qb][hq]);
+                    }
+                }
             };
             if (J & 1) {
                 step(Vs, std::false_type{}, J - 1, sa, sb, pa, pb);
@@ -440,6 +540,56 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
 
         // ---- end of phase: normalise; phase 0 of a two-phase row is parked in LDS rounded to the element type (the
         // reference adds two half-precision SDPA outputs, attention_processor.py:612) and read back by the same lane ----
+        if constexpr (TAIL) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                // softmax denominator of query 16 hq + n: accumulator row 40 = reg 0 of lane 32 + n in tail accumulator hq
+                const float l0 = __shfl(ot[qb][0][0], 32 + (lane & 15));
+                const float l1 = __shfl(ot[qb][1][0], 32 + (lane & 15));
+                const float inv = ((ph == 1) ? w2 : 1.0f) / ((col & 16) ? l1 : l0);
+                uint32_t pk[12];
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) {               // jj < 4: rows 8 jj + 4 hi + 0..3 of query `col`;  4, 5: tail half hq = jj - 4,
+                    float v[4];                                //          rows 32 + 4 (lane >> 4) + 0..3 of query 16 hq + (lane & 15)
+                    if (jj < 4) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) v[e2] = o[qb][0][4 * jj + e2] * inv;
+                    } else {
+                        const float it = __shfl(inv, (lane & 15) + 16 * (jj - 4));
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) v[e2] = ot[qb][jj - 4][e2] * it;
+                    }
+                    if (ph == 1) {
+                        const uint2 prev = *reinterpret_cast<const uint2*>(park + (qb * 6 + jj) / 2 * 1024 + ((qb * 6 + jj) & 1) * 8);
+                        v[0] += E::lo(prev.x); v[1] += E::hi(prev.x); v[2] += E::lo(prev.y); v[3] += E::hi(prev.y);
+                    }
+                    pk[2 * jj] = E::pack2(v[0], v[1]);
+                    pk[2 * jj + 1] = E::pack2(v[2], v[3]);
+                }
+                if (ph == 0 && nph == 2) {
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj)
+                        *reinterpret_cast<uint2*>(park + (qb * 6 + jj) / 2 * 1024 + ((qb * 6 + jj) & 1) * 8) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
+                } else {
+                    const int q = q0 + qb * 32 + col;
+                    if (q < p.N) {
+                        bf16_t* orow = p.out + ((size_t)b * p.N + q) * p.out_ld + h * D;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+                            *reinterpret_cast<uint2*>(orow + 8 * jj + 4 * hi) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
+                    }
+                    if (lane < 32) {                           // lanes 32..47 hold rows 40..43 (the denominators), 48..63 rows 44..47
+#pragma unroll
+                        for (int hq = 0; hq < 2; ++hq) {
+                            const int qt = q0 + qb * 32 + 16 * hq + (lane & 15);
+                            if (qt < p.N)
+                                *reinterpret_cast<uint2*>(p.out + ((size_t)b * p.N + qt) * p.out_ld + h * D + 32 + 4 * (lane >> 4)) =
+                                    make_uint2(pk[8 + 2 * hq], pk[9 + 2 * hq]);
+                        }
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             const float mine = o[qb][L_DT][L_REG];             // accumulator row 40 (the softmax denominator): lanes with hi == L_HI
@@ -474,6 +624,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                 }
             }
         }
+        }
     }
     if ((VAR & 4096) && lane == 0) {       // (the kernel's real output is garbage in this variant: the counters overwrite its head)
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out);
@@ -486,7 +637,8 @@ template <bool F16, int THR, int VAR>
 int launch_attn40(const AttnParams& p, hipStream_t s) {
     static bool attr_set = false;
     auto kern = attn40_kernel<F16, THR, VAR>;
-    constexpr int LDS_BYTES = (VAR & 512) ? 100 * 1024 : (VAR & 128) ? LDS_BYTES_D : 2 * BUF + PARK;
+    constexpr int PARKB = (VAR & 8192) ? PARK_T : PARK;
+    constexpr int LDS_BYTES = (VAR & 512) ? 100 * 1024 : (VAR & 128) ? NRING * BUF_D + PARKB + 1024 : 2 * BUF + PARKB;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return imd_set_error("attention(d=40): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -499,8 +651,12 @@ int launch_attn40(const AttnParams& p, hipStream_t s) {
 
 }  // namespace
 
-// variant: 6 = pipelined kernel, compiler's own interleave; 7 = with the explicit MFMA / VALU interleave hints;
-//          8 = as 7 with the deferred-maximum bound 2^12 instead of 2^8
+// variant: 10 (default) = software-pipelined kernel, pinned MFMA / VALU interleave, head-dim rows 32..40 of P.V on
+//          v_mfma_f32_16x16x32 (VAR & 8192), K / V^T staged by LDS-DMA when the caller guarantees K's pad column
+//          (imd_attn_params.k_pad_one), through registers otherwise;
+//          9 = round-2 default (P.V as two 32x32x16 row blocks), same staging rule;  7 = 9 with register staging always;
+//          6 = 7 with the compiler's own interleave;  8 = 7 with the deferred-maximum bound 2^12 instead of 2^8
+//          20..39 (only when built with -DIMD_ABLATIONS): timing ablations with WRONG results (tools/attn_bench.py)
 int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (variant) {
@@ -509,28 +665,36 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
         case 9:             // LDS-DMA staging: needs the caller's guarantee that K's pad column holds 1.0
             if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128>(p, s) : launch_attn40<false, 8, 1 | 128>(p, s);
             return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
+        case 7: return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
+        case 11:            // the 16x16x32 tail with register staging always
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+#ifdef IMD_ABLATIONS
         // timing ablations of variant 7 (WRONG results; tools/attn_bench.py --variants ...)
-        case 10: return launch_attn40<false, 8, 1 | 4>(p, s);         // no exp2
-        case 11: return launch_attn40<false, 8, 1 | 8>(p, s);         // no loop barrier
-        case 12: return launch_attn40<false, 8, 1 | 16>(p, s);        // no loads / LDS stores in the loop
-        case 13: return launch_attn40<false, 8, 1 | 32>(p, s);        // no P.V MFMAs
-        case 14: return launch_attn40<false, 8, 1 | 64>(p, s);        // 2 of 6 QK^T MFMAs
-        case 15: return launch_attn40<false, 8, 1 | 8 | 16>(p, s);    // no barrier, no staging
-        case 16: return launch_attn40<false, 8, 1 | 256>(p, s);       // one LDS fragment read per step
-        case 17: return launch_attn40<false, 8, 1 | 512>(p, s);       // one workgroup per CU
-        case 18: return launch_attn40<false, 8, 1 | 4 | 16 | 256>(p, s);   // MFMAs + pack only
-        case 19: return launch_attn40<false, 8, 1 | 32 | 64 | 16>(p, s);   // 2 MFMAs per step, everything else
-        case 20: return launch_attn40<false, 8, 1 | 128 | 2048>(p, s);     // LDS-DMA variant without the packed-max / overflow test
-        case 21: return launch_attn40<false, 8, 1 | 128 | 4096>(p, s);     // cycle counters (tools/attn_bench.py --cycles)
-        case 22: return launch_attn40<false, 8, 1 | 128 | 4096 | 512>(p, s);   // ... with one workgroup per CU
+        case 20: return launch_attn40<false, 8, 1 | 4>(p, s);         // no exp2
+        case 21: return launch_attn40<false, 8, 1 | 8>(p, s);         // no loop barrier
+        case 22: return launch_attn40<false, 8, 1 | 16>(p, s);        // no loads / LDS stores in the loop
+        case 23: return launch_attn40<false, 8, 1 | 32>(p, s);        // no P.V MFMAs
+        case 24: return launch_attn40<false, 8, 1 | 64>(p, s);        // 2 of 6 QK^T MFMAs
+        case 25: return launch_attn40<false, 8, 1 | 8 | 16>(p, s);    // no barrier, no staging
+        case 26: return launch_attn40<false, 8, 1 | 256>(p, s);       // one LDS fragment read per step
+        case 27: return launch_attn40<false, 8, 1 | 512>(p, s);       // one workgroup per CU
+        case 28: return launch_attn40<false, 8, 1 | 4 | 16 | 256>(p, s);   // MFMAs + pack only
+        case 29: return launch_attn40<false, 8, 1 | 32 | 64 | 16>(p, s);   // 2 MFMAs per step, everything else
+        case 30: return launch_attn40<false, 8, 1 | 128 | 2048>(p, s);     // LDS-DMA variant without the packed-max / overflow test
+        case 31: return launch_attn40<false, 8, 1 | 128 | 4096>(p, s);     // cycle counters (tools/attn_bench.py --cycles)
+        case 32: return launch_attn40<false, 8, 1 | 128 | 4096 | 512>(p, s);   // ... with one workgroup per CU
         // one workgroup per CU (a lone wave per SIMD): what is that wave's step made of
-        case 23: return launch_attn40<false, 8, 1 | 128 | 512>(p, s);
-        case 24: return launch_attn40<false, 8, 1 | 128 | 512 | 4>(p, s);              // no exp2
-        case 25: return launch_attn40<false, 8, 1 | 128 | 512 | 16>(p, s);             // no staging
-        case 26: return launch_attn40<false, 8, 1 | 128 | 512 | 32>(p, s);             // no P.V MFMAs
-        case 27: return launch_attn40<false, 8, 1 | 128 | 512 | 32 | 64>(p, s);        // 2 MFMAs per step
-        case 28: return launch_attn40<false, 8, 1 | 128 | 512 | 4 | 16 | 2048>(p, s);  // MFMAs, packs and fragment reads only
-        case 29: return launch_attn40<false, 8, 1 | 128 | 512 | 8>(p, s);              // no barrier
-        default: return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
+        case 33: return launch_attn40<false, 8, 1 | 128 | 512>(p, s);
+        case 34: return launch_attn40<false, 8, 1 | 128 | 512 | 4>(p, s);              // no exp2
+        case 35: return launch_attn40<false, 8, 1 | 128 | 512 | 16>(p, s);             // no staging
+        case 36: return launch_attn40<false, 8, 1 | 128 | 512 | 32>(p, s);             // no P.V MFMAs
+        case 37: return launch_attn40<false, 8, 1 | 128 | 512 | 32 | 64>(p, s);        // 2 MFMAs per step
+        case 38: return launch_attn40<false, 8, 1 | 128 | 512 | 4 | 16 | 2048>(p, s);  // MFMAs, packs and fragment reads only
+        case 39: return launch_attn40<false, 8, 1 | 128 | 512 | 8>(p, s);              // no barrier
+#endif
+        case 10:
+        default:
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
     }
 }

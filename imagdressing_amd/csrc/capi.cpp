@@ -86,7 +86,13 @@ int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long coun
 
 int imd_set_tuning(int knob, int value) {
     switch (knob) {
-        case 0: IMD_REQUIRE(value >= 1 && value <= 29, "set_tuning: attention variant for head dim 40 must be 1..29 (10..29: timing ablations, wrong results)"); g_attn_qw40 = value; return 0;
+        case 0:
+#ifdef IMD_ABLATIONS
+            IMD_REQUIRE(value >= 1 && value <= 39, "set_tuning: attention variant for head dim 40 must be 1..39 (20..39: timing ablations, WRONG results)");
+#else
+            IMD_REQUIRE(value >= 1 && value <= 11, "set_tuning: attention variant for head dim 40 must be 1..11 (the timing ablations 20..39 exist only in -DIMD_ABLATIONS builds)");
+#endif
+            g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
         case 2: g_gemm_flags = value & 511; return 0;   // (bit 8: row_linear staged epilogue, A/B only)
         default: return imd_set_error("set_tuning: unknown knob %d", knob);
@@ -167,7 +173,7 @@ int imd_softmax_rows(const float* s, int s_ld, uint16_t* p, int p_ld, int rows, 
 
 int imd_ddim_cfg_step(const imd_ddim_params* p, void* stream) {
     IMD_REQUIRE(p && p->z && p->eps, "ddim_cfg_step: null pointer");
-    IMD_REQUIRE(p->sqrt_a_t > 0.f, "ddim_cfg_step: sqrt(alpha_t) must be positive");
+    IMD_REQUIRE(p->coefs != nullptr || p->sqrt_a_t > 0.f, "ddim_cfg_step: sqrt(alpha_t) must be positive");
     return imd_launch_ddim_cfg_step(*p, (hipStream_t)stream);
 }
 

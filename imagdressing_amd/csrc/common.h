@@ -32,6 +32,9 @@ template <> struct El<false> {
     static __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {       // D[16x16] += A[16x32] B[32x16]
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
 };
 
 template <> struct El<true> {
@@ -45,6 +48,9 @@ template <> struct El<true> {
     static __device__ __forceinline__ bf16_t fromf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
     static __device__ __forceinline__ f32x16 mfma(const uint4& a, const uint4& b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
 
@@ -69,6 +75,9 @@ template <bool F16> __device__ __forceinline__ uint4 pack8(const float* f) {
 //   D: lane l, reg r holds  D[(r&3) + 8*(r>>2) + 4*(l>>5)][l & 31]
 // Only the A/B *pairing* of contraction slots matters for the result (a sum), so callers are
 // free to permute the contraction index as long as A and B use the same permutation.
+// D[16x16] += A[16x32] * B[32x16]  (El<F16>::mfma16, v_mfma_f32_16x16x32_*; half the work in about half the matrix-pipe time):
+//   A: lane l holds row  i = l & 15, contraction slots 8*(l>>4) .. +7      B: lane l holds col j = l & 15, same slots
+//   D: lane l, reg r (0..3) holds  D[4*(l>>4) + r][l & 15]
 
 // row of D held by (reg r, half hi)
 __device__ __forceinline__ int mfma_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

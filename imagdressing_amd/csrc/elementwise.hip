@@ -19,6 +19,10 @@ namespace {
 template <bool F16>
 __global__ __launch_bounds__(256) void ddim_cfg_step_kernel(const DdimParams p) {
     const long total = (long)p.B * p.HW;                   // one thread per pixel (4 channels = 16 B)
+    float sa_t = p.sqrt_a_t, s1_t = p.sqrt_1m_a_t, sa_p = p.sqrt_a_prev, s1_p = p.sqrt_1m_a_prev, sa_n = p.sqrt_a_next, s1_n = p.sqrt_1m_a_next;
+    if (p.coefs) {                                         // schedule coefficients from device memory (HIP-graph replay of a step)
+        sa_t = p.coefs[0]; s1_t = p.coefs[1]; sa_p = p.coefs[2]; s1_p = p.coefs[3]; sa_n = p.coefs[4]; s1_n = p.coefs[5];
+    }
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         const float4 z = reinterpret_cast<const float4*>(p.z)[i];
         const float4 ec = reinterpret_cast<const float4*>(p.eps)[i];
@@ -38,10 +42,10 @@ __global__ __launch_bounds__(256) void ddim_cfg_step_kernel(const DdimParams p) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float eps = u[e] + p.guidance * (c[e] - u[e]);
-            const float x0 = (zz[e] - p.sqrt_1m_a_t * eps) / p.sqrt_a_t;
-            float zn = p.sqrt_a_prev * x0 + p.sqrt_1m_a_prev * eps;
+            const float x0 = (zz[e] - s1_t * eps) / sa_t;
+            float zn = sa_p * x0 + s1_p * eps;
             if (p.mask) {
-                const float proper = p.sqrt_a_next * zi[e] + p.sqrt_1m_a_next * nz[e];
+                const float proper = sa_n * zi[e] + s1_n * nz[e];
                 zn = (1.f - mk) * proper + mk * zn;
             }
             zz[e] = zn;

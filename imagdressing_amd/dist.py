@@ -100,14 +100,27 @@ def garment_features_broadcast(pipe, ref_latents: torch.Tensor, cloth_tokens: to
     layout = [e for e in feature_layout(runet, hw) if e[0].endswith("attn1.processor")]   # only attn1 is consumed
     names = [n for n, _ in layout]
     total = sum(s[1] * s[2] for _, s in layout)
+    # ONE packed broadcast: [features | status] (status LAST: the feature views keep the buffer's alignment).  The status element (0 = ok) travels with the payload, so a failure on rank 0
+    # (layout mismatch, an exception in the garment pass) raises on EVERY rank instead of leaving the others to denoise NaNs or
+    # to hang in the next collective after rank 0 has left.
+    flat = torch.empty(total + 1, dtype=runet.dtype, device=pipe.device)
+    err = None
     if rank() == 0:
-        feats = pipe.garment_features(ref_latents, cloth_tokens)
-        flat, lay0 = pack_features({n: feats[n].to(runet.dtype) for n in names}, names)
-        if lay0 != layout:       # never leave the other ranks blocked in the broadcast: send what they expect, then raise
-            flat = torch.full((total,), float("nan"), dtype=runet.dtype, device=pipe.device)
-    else:
-        flat = torch.empty(total, dtype=runet.dtype, device=pipe.device)
+        try:
+            feats = pipe.garment_features(ref_latents, cloth_tokens)
+            body, lay0 = pack_features({n: feats[n].to(runet.dtype) for n in names}, names)
+            if lay0 != layout:
+                raise RuntimeError(f"garment feature layout mismatch: derived {layout[:2]}..., garment UNet produced {lay0[:2]}...")
+            flat[:total] = body
+            flat[total] = 0.0
+        except Exception as e:       # noqa: BLE001  (re-raised below, after the other ranks have been released)
+            err = e
+            flat.zero_()
+            flat[total] = 1.0
     broadcast_packed(flat, 0)
-    if rank() == 0 and lay0 != layout:
-        raise RuntimeError(f"garment feature layout mismatch: derived {layout[:2]}..., garment UNet produced {lay0[:2]}...")
+    if err is not None:
+        raise err
+    if rank() != 0 and float(flat[total].item()) != 0.0:
+        raise RuntimeError("rank 0 failed while computing the garment features (status flag of the packed broadcast); see its traceback")
+    flat = flat[:total]
     return unpack_features(flat, layout)

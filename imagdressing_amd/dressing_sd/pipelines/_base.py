@@ -57,6 +57,21 @@ class PipelineBase:
 
     def _init_common(self, *, vae, reference_unet, unet, tokenizer, text_encoder, image_encoder, ImgProj, scheduler,
                      safety_checker=None, feature_extractor=None, controlnet=None):
+        from ...hub import PendingModel
+
+        def ready(m):          # a ``from_pretrained`` handle that never met ``.to(device=...)``: build it now (default device)
+            return m._build() if isinstance(m, PendingModel) else m
+        vae, reference_unet, unet, controlnet = ready(vae), ready(reference_unet), ready(unet), ready(controlnet)
+        text_encoder, image_encoder = ready(text_encoder), ready(image_encoder)
+        for role, m in (("unet", unet), ("reference_unet", reference_unet), ("controlnet", controlnet)):
+            if isinstance(m, torch.nn.Module) and not hasattr(m, "forward_nhwc"):        # e.g. a stock diffusers UNet2DConditionModel
+                raise TypeError(
+                    f"IMAGDressing_v1({role}=...): got a {type(m).__module__}.{type(m).__name__}.  These pipelines drive the MI355X engine "
+                    "UNet (imagdressing_amd.unet.UNet2DConditionModel / ControlNetModel; NHWC, fused CFG batch) -- build it from the same "
+                    "checkpoint with `UNet2DConditionModel.from_pretrained(dir, subfolder='unet').to(dtype=torch.float16, device='cuda')` "
+                    "imported from imagdressing_amd.unet, or put <repo>/compat on sys.path so that `from diffusers import "
+                    "UNet2DConditionModel` resolves to it (INTEGRATION.md section 1).  The attention PROCESSORS alone also work on a "
+                    "stock diffusers UNet (unet.set_attn_processor), but then the stock diffusers pipeline has to drive it.")
         self.vae, self.reference_unet, self.unet = vae, reference_unet, unet
         self.tokenizer, self.text_encoder, self.image_encoder = tokenizer, text_encoder, image_encoder
         self.ImgProj, self.scheduler, self.controlnet = ImgProj, scheduler, controlnet
@@ -77,6 +92,13 @@ class PipelineBase:
         return self.unet.device
 
     _execution_device = device
+
+    def enable_step_graph(self, flag: bool = True):
+        """Opt in to HIP-graph replay of the DDIM denoising step (see ``denoise``): same kernels, same arithmetic, one graph launch
+        per step instead of ~500 kernel launches.  Worth it where the loop is host-bound (small batches); ignored for UniPC, step
+        callbacks, traces and per-step ControlNet gating."""
+        self._step_graph = bool(flag)
+        return self
 
     def enable_vae_slicing(self):
         self.vae.enable_slicing()
@@ -182,28 +204,75 @@ class PipelineBase:
         multistep = hasattr(sch, "step_guided")        # UniPC: latent updates are host-computed linear combinations
         if multistep and inp is not None:
             raise NotImplementedError("the inpainting blend is defined on the DDIM step (…inpainting.py:487-500)")
-        for i, t in enumerate(timesteps):
+        keeps = None if control is None else [control.get("keep", [1.0] * len(timesteps))[i] for i in range(len(timesteps))]
+        ctrl_scale = 0.0 if control is None else float(control.get("scale", 1.0))
+
+        def ddim_step(t, i=None, coefs=None):
+            """ControlNet + UNet + CFG / DDIM / blend / next UNet input for one timestep; ``t`` a Python int (eager) or a device
+            scalar with ``coefs`` the device-side schedule coefficients (graph replay: nothing step-specific is baked in)."""
             down = mid = None
             if control is not None:
-                keep = control.get("keep", [1.0] * len(timesteps))[i]
-                down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, float(control.get("scale", 1.0)) * keep)
+                down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, ctrl_scale * (keeps[0] if i is None else keeps[i]))
             eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid)
+            kw = {}
+            if inp is not None:
+                kw = dict(mask=inp["mask"], z_img=inp["z_img"], noise=inp["noise"])
+            if coefs is not None:
+                ops.ddim_cfg_step(z, eps, x_in.view(2 * B, HW, 8), guidance=float(guidance_scale), coefs=coefs, **kw)
+            else:
+                if inp is not None:
+                    kw["a_next"] = sch.alpha(timesteps[i + 1]) if i < len(timesteps) - 1 else None
+                ops.ddim_cfg_step(z, eps, x_in.view(2 * B, HW, 8), guidance=float(guidance_scale), a_t=sch.alpha(timesteps[i]),
+                                  a_prev=sch.alpha_prev(timesteps[i]), **kw)
+
+        use_graph = (getattr(self, "_step_graph", False) and not multistep and callback is None and trace is None
+                     and len(timesteps) > 2 and (keeps is None or len(set(keeps)) == 1) and ops.ATTN_EVENT_HOOK is None)
+        if use_graph:
+            # HIP-graph replay of the denoising step (opt-in, ``enable_step_graph``): step 0 runs eagerly on the pipeline's side stream
+            # (it also fills the step-invariant K / V caches of the processors), step 1 is CAPTURED (not executed) into a graph whose
+            # only per-step inputs are two device scalars -- the timestep and the six schedule coefficients -- and the graph is then
+            # replayed for steps 1 .. S-1: ~500 kernel launches per step become one hipGraphLaunch (the loop is host-bound at batch 1).
+            steps_n = len(timesteps)
+            t_table = torch.tensor(timesteps, dtype=torch.float32).to(dev)
+            rows = []
+            for i, t in enumerate(timesteps):
+                a_next = (sch.alpha(timesteps[i + 1]) if i < steps_n - 1 else None) if inp is not None else None
+                rows.append(ops.ddim_coefs(sch.alpha(t), sch.alpha_prev(t), a_next))
+            coef_table = torch.tensor(rows, dtype=torch.float32).to(dev)
+            t_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+            coef_dev = torch.zeros(6, dtype=torch.float32, device=dev)
+            side = self.__dict__.get("_graph_stream")
+            if side is None:
+                side = self._graph_stream = torch.cuda.Stream(device=dev)
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                t_dev.copy_(t_table[0:1]); coef_dev.copy_(coef_table[0])
+                ddim_step(t_dev, coefs=coef_dev)
+                g = torch.cuda.CUDAGraph()
+                g.capture_begin()
+                try:
+                    ddim_step(t_dev, coefs=coef_dev)
+                finally:
+                    g.capture_end()
+                for i in range(1, steps_n):
+                    t_dev.copy_(t_table[i:i + 1]); coef_dev.copy_(coef_table[i])
+                    g.replay()
+            cur.wait_stream(side)
+            self._last_step_graph = g          # keep the executable graph alive until the next call (replays may still be in flight)
+            return z.view(B, h, w, Cl).permute(0, 3, 1, 2).contiguous()
+        for i, t in enumerate(timesteps):
             if multistep:
+                down = mid = None
+                if control is not None:
+                    down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, ctrl_scale * keeps[i])
+                eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid)
                 z = sch.step_guided(eps.view(2 * B, HW, Cl), z, float(guidance_scale))
                 # emit the next 16-bit UNet input (both CFG halves) from z: the fused step with eps = 0, alpha = 1 is the identity on z
                 ops.ddim_cfg_step(z, ops.workspace("zero_eps", (2 * B, HW, Cl), torch.float32, dev), x_in.view(2 * B, HW, 8),
                                   guidance=1.0, a_t=1.0, a_prev=1.0)
-                if trace is not None:
-                    trace.append(z.clone())
-                if callback is not None and i % callback_steps == 0:
-                    callback(i, t, z.view(B, h, w, Cl).permute(0, 3, 1, 2))
-                continue
-            kw = {}
-            if inp is not None:
-                a_next = sch.alpha(timesteps[i + 1]) if i < len(timesteps) - 1 else None
-                kw = dict(mask=inp["mask"], z_img=inp["z_img"], noise=inp["noise"], a_next=a_next)
-            ops.ddim_cfg_step(z, eps, x_in.view(2 * B, HW, 8), guidance=float(guidance_scale), a_t=sch.alpha(t),
-                              a_prev=sch.alpha_prev(t), **kw)
+            else:
+                ddim_step(t, i)
             if trace is not None:
                 trace.append(z.clone())
             if callback is not None and i % callback_steps == 0:

@@ -22,12 +22,32 @@ WEIGHT_FILES = ("diffusion_pytorch_model.safetensors", "model.safetensors", "dif
                 "diffusion_pytorch_model.bin", "pytorch_model.bin")
 
 
+def resolve_model_dir(name: str) -> str:
+    """A local directory for ``name``: the path itself, else -- for a hub id such as "SG161222/Realistic_Vision_V4.0_noVAE", which
+    the reference scripts hard-code (inference_IMAGdressing.py:42-52) -- ``$IMD_MODEL_ROOT/<org>/<name>``, else the newest snapshot
+    of the local Hugging Face cache (``$HF_HOME`` / ``~/.cache/huggingface``).  Nothing is downloaded."""
+    if os.path.isdir(name):
+        return name
+    roots = [os.environ.get("IMD_MODEL_ROOT")]
+    for r in roots:
+        if r and os.path.isdir(os.path.join(r, name)):
+            return os.path.join(r, name)
+    hf = os.environ.get("HF_HOME") or os.path.join(os.path.expanduser("~"), ".cache", "huggingface")
+    snap = os.path.join(hf, "hub", "models--" + name.replace("/", "--"), "snapshots")
+    if os.path.isdir(snap):
+        cands = sorted((os.path.join(snap, d) for d in os.listdir(snap)), key=os.path.getmtime)
+        if cands:
+            return cands[-1]
+    return name
+
+
 def read_pretrained_dir(path: str, subfolder: Optional[str] = None):
     """-> (state dict on the CPU, config dict) of a local Hugging Face model directory."""
+    path = resolve_model_dir(path)
     d = os.path.join(path, subfolder) if subfolder else path
     if not os.path.isdir(d):
-        raise FileNotFoundError(f"from_pretrained: {d!r} is not a local directory (this build has no hub access; "
-                                "download the model and pass its path)")
+        raise FileNotFoundError(f"from_pretrained: {d!r} is not a local directory (this build has no hub access; download the "
+                                "model and pass its path, or put it under $IMD_MODEL_ROOT/<org>/<name>)")
     cfg = {}
     cj = os.path.join(d, "config.json")
     if os.path.isfile(cj):
@@ -52,17 +72,23 @@ class PendingModel:
         self.config = SimpleNamespace(**config)
 
     def to(self, *args, dtype=None, device=None, **unused):
+        """``.to(dtype=, device=)`` builds the engine; ``.to(dtype)`` alone (or ``from_pretrained(torch_dtype=...)``,
+        ..._controlnetpose.py:137-138) only records the element type -- the engine is built when the device arrives, or on first use."""
         for a in args:
             if isinstance(a, torch.dtype):
                 dtype = a
             elif isinstance(a, (str, torch.device, int)):
                 device = a
-        if dtype is None:
-            dtype = torch.float16                 # the reference's dtype (inference_IMAGdressing.py:42-52)
+        if dtype is not None:
+            self.__dict__["_dtype"] = dtype
         if device is None:
-            device = "cuda"
+            return self
+        return self._build(device)
+
+    def _build(self, device="cuda"):
+        dtype = self.__dict__.get("_dtype") or torch.float16      # the reference's dtype (inference_IMAGdressing.py:42-52)
         eng = self._cls(self._sd, self._engine_config, device, dtype)
-        self._sd = None
+        self.__dict__["_sd"] = None
         return eng
 
     def __getattr__(self, name):
@@ -118,11 +144,18 @@ class PretrainedMixin:
         return {}
 
     def load_state_dict(self, state_dict, strict: bool = True):
-        """Rebuild the engine in place from a diffusers-layout state dict (``ref_unet.load_state_dict(ref_unet_dict)``,
-        inference_IMAGdressing.py:114); installed attention processors are kept."""
+        """Rebuild the engine from a diffusers-layout state dict (``ref_unet.load_state_dict(ref_unet_dict)``,
+        inference_IMAGdressing.py:114); installed attention processors are kept.  A FRESH instance is built first and swapped
+        in only on success, so a bad state dict (missing keys, wrong shapes) leaves this object exactly as it was.
+        ``strict=False`` is refused: the engines repack every weight at build time and cannot run with a partial set."""
+        if not strict:
+            raise NotImplementedError(f"{type(self).__name__}.load_state_dict(strict=False): the engine needs the complete diffusers-layout "
+                                      "state dict (weights are repacked for the kernels at build time)")
         procs = dict(self.attn_processors) if hasattr(self, "attn_processors") else None
         cfg = getattr(self, "_ctor_config", None)
-        self.__init__(state_dict, cfg, self.device, self.dtype)
+        fresh = type(self)(state_dict, cfg, self.device, self.dtype)
         if procs is not None:
-            self.set_attn_processor(procs)
+            fresh.set_attn_processor(procs)
+        self.__dict__.clear()
+        self.__dict__.update(fresh.__dict__)
         return torch.nn.modules.module._IncompatibleKeys([], [])

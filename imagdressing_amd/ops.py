@@ -65,7 +65,9 @@ _ws: Dict[Tuple, torch.Tensor] = {}
 
 
 def workspace(tag: str, shape: Sequence[int], dtype, device, init=None) -> torch.Tensor:
-    key = (tag, tuple(shape), dtype, str(device))
+    """Persistent scratch keyed by (tag, shape, dtype, device, CURRENT STREAM): launches on one stream are ordered, so one buffer
+    per stream is race-free; two pipelines driven on two streams of one process get separate buffers instead of silently sharing."""
+    key = (tag, tuple(shape), dtype, str(device), _stream())
     t = _ws.get(key)
     if t is None:
         t = torch.zeros(tuple(shape), dtype=dtype, device=device)
@@ -90,7 +92,27 @@ def k_buffer(shape: Sequence[int], D: int, dtype, device, tag: Optional[str] = N
 
 
 def clear_workspaces():
+    """Drop every persistent scratch buffer (attention operand buffers, GroupNorm partials, split-K slabs, cached fp8 K / V)."""
     _ws.clear()
+    _splitk_ws.clear()
+    _splitk_cnt.clear()
+    for fn in _clear_hooks:
+        fn()
+
+
+_clear_hooks = []          # modules holding device-side caches of their own register a clearer here (adapter/attention_processor.py)
+
+# ---------------------------------------------------------------------------------------------
+# algorithmic FLOP accounting (bench.py: `flops_per_step`): when FLOP_COUNTER is a dict the matrix-shaped wrappers add the
+# FLOPs their launch is DEFINED to compute (2 M N K per GEMM / conv, 4 N L d per attention key set; padding excluded).
+# ---------------------------------------------------------------------------------------------
+FLOP_COUNTER: Optional[dict] = None
+
+
+def _count(kind: str, flops: float):
+    c = FLOP_COUNTER
+    if c is not None:
+        c[kind] = c.get(kind, 0.0) + float(flops)
 
 
 def attn_padded_dims(D: int) -> Tuple[int, int]:
@@ -190,6 +212,7 @@ def conv_gemm(
             out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else dt, device=x.device)
         p.out = _dev(out, torch.float32 if out_f32 else dt, "out")
         p.out_ld = n_out if out_ld is None else out_ld
+    _count("gemm_conv", 2.0 * M * N * K)
     lib = L.load()
     if gn is not None:
         p.gn_a, p.gn_b, p.gn_silu = _dev(gn[0], torch.float32, "gn_a"), _dev(gn[1], torch.float32, "gn_b"), int(gn[2])
@@ -234,28 +257,30 @@ def conv_gemm(
     return out
 
 
-_splitk_ws: Dict[str, torch.Tensor] = {}
+_splitk_ws: Dict[Tuple, torch.Tensor] = {}
 
 
-_splitk_cnt: Dict[str, torch.Tensor] = {}
+_splitk_cnt: Dict[Tuple, torch.Tensor] = {}
 
 
 def splitk_counters(device) -> torch.Tensor:
     """Zeroed per-tile arrival counters of the in-kernel split-K reduction (include/imagdressing_hip.h::splitk_counters); every
     launch leaves them zero, launches are stream-ordered, so one array per device serves all of them."""
-    t = _splitk_cnt.get(str(device))
+    key = (str(device), _stream())
+    t = _splitk_cnt.get(key)
     if t is None:
         t = torch.zeros(16384, dtype=torch.int32, device=device)
-        _splitk_cnt[str(device)] = t
+        _splitk_cnt[key] = t
     return t
 
 
 def splitk_workspace(nfloats: int, device) -> torch.Tensor:
-    """Grow-only fp32 scratch for split-K partial tiles (stream-ordered reuse)."""
-    t = _splitk_ws.get(str(device))
+    """Grow-only fp32 scratch for split-K partial tiles (stream-ordered reuse: one per device AND stream)."""
+    key = (str(device), _stream())
+    t = _splitk_ws.get(key)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(nfloats, 1 << 22), dtype=torch.float32, device=device)
-        _splitk_ws[str(device)] = t
+        _splitk_ws[key] = t
     return t
 
 
@@ -317,6 +342,7 @@ def ff_geglu_fused(x2d: torch.Tensor, packed: dict, ln_eps: float = 1e-5, out: O
     p.w2, p.b2, p.out = _dev(packed["w2"], dt, "w2"), _dev(packed["b2"], torch.float32, "b2"), _dev(out, dt, "out")
     p.M, p.C, p.inner, p.x_ld, p.out_ld = M, packed["C"], packed["inner"], x2d.stride(0), out.stride(0)
     p.ln, p.ln_eps, p.dtype = int(packed["ln"]), float(ln_eps), _code(x2d, "x")
+    _count("gemm_conv", 2.0 * M * packed["C"] * 2 * packed["inner"] + 2.0 * M * packed["inner"] * packed["C"])
     L.check(L.load().imd_ff_geglu(C.byref(p), _stream()))
     return out
 
@@ -358,6 +384,9 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
     p.out_ld = H * D if out_ld is None else out_ld
     p.causal = int(causal)
     p.k_pad_one = int(bool(k_pad_one))
+    if FLOP_COUNTER is not None:          # (reads scale2 back: counting mode only)
+        rows2 = 0 if (k2 is None or scale2 is None) else int((scale2 != 0).sum().item())
+        _count("attention", 4.0 * H * N * D * (B * L1 * (0.5 if causal else 1.0) + rows2 * L2))
     hook = ATTN_EVENT_HOOK
     if hook is not None and hook["match"](B=B, H=H, N=N, D=D, L1=L1, L2=L2 if k2 is not None else 0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -528,8 +557,15 @@ def layer_norm(x: torch.Tensor, gamma, beta, eps=1e-5, out=None) -> torch.Tensor
     return out
 
 
-def ddim_cfg_step(z, eps, x_next, *, guidance, a_t, a_prev, mask=None, z_img=None, noise=None, a_next=None):
-    """z [B,HW,4] fp32 (in place); eps [2B,HW,4] fp32; x_next [2B,HW,8] bf16 or None."""
+def ddim_coefs(a_t, a_prev, a_next=None):
+    """The six schedule coefficients of one DDIM step in the order imd_ddim_params.coefs reads them."""
+    an = (1.0, 0.0) if a_next is None else (a_next ** 0.5, (1 - a_next) ** 0.5)
+    return [a_t ** 0.5, (1 - a_t) ** 0.5, a_prev ** 0.5, (1 - a_prev) ** 0.5, an[0], an[1]]
+
+
+def ddim_cfg_step(z, eps, x_next, *, guidance, a_t=1.0, a_prev=1.0, mask=None, z_img=None, noise=None, a_next=None, coefs=None):
+    """z [B,HW,4] fp32 (in place); eps [2B,HW,4] fp32; x_next [2B,HW,8] bf16 or None.  ``coefs``: device fp32 [6]
+    (:func:`ddim_coefs`) read by the kernel instead of a_t / a_prev / a_next (HIP-graph replay of a step)."""
     ensure_device(z.device)
     B, HW = z.shape[0], z.shape[1]
     p = L.DdimParams()
@@ -547,6 +583,9 @@ def ddim_cfg_step(z, eps, x_next, *, guidance, a_t, a_prev, mask=None, z_img=Non
         p.sqrt_a_next, p.sqrt_1m_a_next = 1.0, 0.0
     else:
         p.sqrt_a_next, p.sqrt_1m_a_next = a_next ** 0.5, (1 - a_next) ** 0.5
+    p.coefs = _opt(coefs, torch.float32, "coefs")
+    if coefs is not None and coefs.numel() < 6:
+        raise L.ImdError("ddim_cfg_step: coefs needs 6 fp32 values")
     L.check(L.load().imd_ddim_cfg_step(C.byref(p), _stream()))
     return z
 

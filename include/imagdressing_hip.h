@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 4
+#define IMD_ABI_VERSION 5
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -147,6 +147,9 @@ typedef struct imd_ddim_params {
     const float* noise;   /* [B, HW, 4] */
     float sqrt_a_next, sqrt_1m_a_next;
     int dtype;            /* element type of x_next */
+    const float* coefs;   /* NULL, or DEVICE pointer to 6 fp32 {sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev, sqrt_a_next,
+                           * sqrt_1m_a_next} read by the kernel INSTEAD of the host scalars above: lets one captured HIP graph of a
+                           * denoising step serve every timestep (the host refreshes 24 bytes per step, stream-ordered) */
 } imd_ddim_params;
 
 /* library / device */
@@ -189,8 +192,11 @@ int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long coun
                           void* stream);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
-/* performance knobs (results are identical for every setting).  knob 0: head-dim-40 attention kernel variant (default 9: software-pipelined kernel of attention_d40.hip, LDS-DMA staging when
- * imd_attn_params.k_pad_one; 7: register staging; 2 / 5: round-1 kernel; 10..19: timing ablations with WRONG results);
+/* performance knobs (results are identical for every accepted setting up to fp32 summation order).  knob 0: head-dim-40 attention
+ * kernel variant (default 10: software-pipelined kernel of attention_d40.hip with the P.V tail on v_mfma_f32_16x16x32, LDS-DMA
+ * staging when imd_attn_params.k_pad_one; 11: the same with register staging; 9 / 7: the round-2 kernel with the same two staging
+ * rules; 6, 8: scheduling variants of 7; 1..5: round-1 kernel shapes.  Values 20..39 (timing ablations that compute WRONG
+ * results) are accepted only by a library built with -DIMD_ABLATIONS; a normal build rejects them);
  * knob 1: XCD-aware work mapping of the attention grid (0|1);
  * knob 2: GEMM operand-fetch bits (bit0: tap-inner K order for 3x3 convs, bit1: weight loads bypass the L1,
  * bit2: XCD-aware tile order -- each XCD's L2 owns whole row tiles or whole channel tiles, whichever moves fewer bytes;

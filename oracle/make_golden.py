@@ -2,7 +2,7 @@
 (``/root/reference/adapter/attention_processor.py`` and ``adapter/resampler.py``, imported
 verbatim through ``oracle/ref_loader.py``) on seeded fp32 inputs (TEST INFRASTRUCTURE).
 
-Run in the build container only:   python -m oracle.make_golden [base|full|all]
+Run in the build container only:   python -m oracle.make_golden [base|full|geometry|unet|all]
 The fixtures pin ``oracle/processors.py`` and ``oracle/resampler.py`` (tests/test_oracle_golden.py)
 and are what the ``-m gpu`` parity tests compare the HIP path with when /root/reference is absent.
 
@@ -290,10 +290,71 @@ def main_full():
     print("processors_full.pt", os.path.getsize(os.path.join(OUT, "processors_full.pt")) // 1024, "KiB")
 
 
+def main_geometry():
+    """Third fixture file: the reference source at the token counts of the reference scripts' OWN default geometry --
+    width 512 x height 640, garment 640 x 512 (inference_IMAGdressing.py:182-183; latent 80 x 64) -- i.e. the four UNet
+    levels (C, N = M) = (320, 5120), (640, 1280), (1280, 320), (1280, 80) a user of the unchanged scripts hits first.
+    Level 0 takes the software-pipelined d = 40 kernel (N >= 512), the others the generic kernel at d = 80 / 160."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ap, _ = load_reference_adapter()
+    cases = {
+        "hybrid_d40_n5120": hybrid_case(ap, 2400, B=1, N=5120, M=5120, C=320, heads=8, scale=1.0, store_full=False, keep_rows=384),
+        "hybrid_d80_n1280": hybrid_case(ap, 2500, B=1, N=1280, M=1280, C=640, heads=8, scale=1.0, store_full=False, keep_rows=256),
+        "hybrid_d160_n320": hybrid_case(ap, 2600, B=1, N=320, M=320, C=1280, heads=8, scale=1.0, store_full=False, keep_rows=128),
+        "hybrid_d160_n80": hybrid_case(ap, 2700, B=1, N=80, M=80, C=1280, heads=8, scale=1.0, store_full=False, keep_rows=80),
+    }
+    torch.save(cases, os.path.join(OUT, "processors_default_geometry.pt"))
+    print("processors_default_geometry.pt", os.path.getsize(os.path.join(OUT, "processors_default_geometry.pt")) // 1024, "KiB")
+
+
+@torch.no_grad()
+def main_unet():
+    """Fourth fixture file: ONE full-width (859.5 M parameters) SD1.5 UNet forward of the fp32 oracle (oracle/sd15.py -- the
+    restated, UNPINNED diffusers-0.24 UNet -- carrying oracle/processors.py, which IS pinned on the reference source) at
+    t = 481 on seeded weights and inputs, uncond (no garment) and cond (garment tokens on all 16 attn1 layers), for the 64x64
+    latent of BASELINE configs[1] and the 80x64 latent of the reference scripts' default 512x640 geometry.  bench.py
+    measures its `parity` field against these outputs inside the bench process; tests/test_fullsize_gpu.py uses them too.
+    Inputs are regenerated from seeds by tests/cases.py::unet_forward_inputs and digest-checked."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from imagdressing_amd import unet as E
+    from tests.cases import unet_forward_inputs
+    from tests.harness_names import hidden_size_of
+    from . import processors as OP
+    from . import sd15
+    torch.set_num_threads(8)
+    cases = {}
+    boc = E.SD15_CONFIG["block_out_channels"]
+    for key, (lh, lw) in (("latent_64x64", (64, 64)), ("latent_80x64", (80, 64))):
+        d = unet_forward_inputs(lh, lw)
+        o = sd15.UNet2DConditionModel({})
+        o.load_state_dict(d["sd"], strict=True)
+        assert list(o.attn_processors.keys()) == __import__("tests.harness_names", fromlist=["x"]).attn_processor_names(E.SD15_CONFIG)
+        o.set_attn_processor({n: (OP.RefSAttn(n, hidden_size_of(n, boc)) if n.endswith("attn1.processor")
+                                  else OP.CAttn(n, hidden_size_of(n, boc), 768)) for n in o.attn_processors.keys()})
+        for n in d["names"]:
+            o.attn_processors[n].to_k_ref.weight.copy_(d["rw"][n]["k"]); o.attn_processors[n].to_v_ref.weight.copy_(d["rw"][n]["v"])
+        unc = o(d["x"], 481, d["ehs"])
+        cond = o(d["x"], 481, d["ehs"], cross_attention_kwargs={"sa_hidden_states": d["sa"]})
+        cases[key] = dict(kind="unet_forward", lh=lh, lw=lw, t=481, out_uncond=unc.clone(), out_cond=cond.clone(), digests=d["digests"],
+                          torch_version=torch.__version__)
+        print(key, "uncond std", unc.std().item(), "cond-uncond rel rms", ((cond - unc).pow(2).mean().sqrt() / unc.pow(2).mean().sqrt()).item())
+        del o
+    torch.save(cases, os.path.join(OUT, "unet_forward_full.pt"))
+    print("unet_forward_full.pt", os.path.getsize(os.path.join(OUT, "unet_forward_full.pt")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     import sys
-    what = sys.argv[1] if len(sys.argv) > 1 else "all"          # base | full | all
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"          # base | full | geometry | unet | all
     if what in ("base", "all"):
         main()
     if what in ("full", "all"):
         main_full()
+    if what in ("geometry", "all"):
+        main_geometry()
+    if what in ("unet", "all"):
+        main_unet()

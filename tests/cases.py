@@ -67,3 +67,6 @@ def proj_plus_inputs(c):
     clip = seeded(s + 2001, 1, 257, 1280, scale=0.5)
     assert digest(idv) == c["digests"]["id"] and digest(clip) == c["digests"]["clip"]
     return sd, idv, clip
+
+
+from tests.unet_fixture import unet_forward_inputs  # noqa: E402,F401  (re-export; the module itself imports no oracle code)

@@ -36,3 +36,12 @@ def golden_full():
     CacheAttnProcessor2_0 at real head dims (oracle/make_golden.py::main_full)."""
     import torch
     return torch.load(os.path.join(GOLDEN, "processors_full.pt"), weights_only=False)
+
+
+@pytest.fixture(scope="session")
+def golden_geometry():
+    """Reference-source outputs at the token counts of the reference scripts' default geometry, 512 wide x 640 high with a
+    640 x 512 garment (inference_IMAGdressing.py:182-183): (C, N = M) = (320, 5120), (640, 1280), (1280, 320), (1280, 80)
+    (oracle/make_golden.py::main_geometry)."""
+    import torch
+    return torch.load(os.path.join(GOLDEN, "processors_default_geometry.pt"), weights_only=False)

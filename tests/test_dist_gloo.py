@@ -122,3 +122,54 @@ def test_feature_layout_matches_stride2_rounding():
     assert lay["mid_block.attentions.0.transformer_blocks.0.attn1.processor"][1] == 108
     with pytest.raises(ValueError):
         D.feature_layout(pipe.reference_unet, (65, 64))
+
+
+def test_shard_bounds_cover_the_batch_for_every_world_size():
+    """BASELINE configs[3] / [4]: 64 and 32 images over 8 ranks, plus remainders and more ranks than images: the shards are
+    contiguous, disjoint, ordered, cover [0, n) and differ in size by at most one."""
+    from imagdressing_amd import dist as D
+    assert [D.shard_bounds(64, r, 8) for r in range(8)] == [(8 * r, 8 * r + 8) for r in range(8)]
+    assert [D.shard_bounds(32, r, 8) for r in range(8)] == [(4 * r, 4 * r + 4) for r in range(8)]
+    for n in (1, 3, 7, 8, 9, 31, 32, 33, 63, 64, 65):
+        for w in (1, 2, 3, 4, 8):
+            b = [D.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _failing_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pipe, G = _make_pipe()
+
+        def boom(*a, **k):
+            raise RuntimeError("garment pass failed on rank 0")
+        pipe.garment_features = boom            # only rank 0 ever calls it
+        try:
+            pipe._sa_states(torch.zeros(1, 4, 16, 16), torch.zeros(2, 16, 64), True)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_rank0_failure_raises_on_every_rank():
+    """A failure of the garment pass on rank 0 travels in the status element of the ONE packed broadcast: every rank raises,
+    none is left denoising garbage or blocked in a later collective (advisor finding, round 2)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert "failed on rank 0" in res[0] and "rank 0 failed" in res[1], res

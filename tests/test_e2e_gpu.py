@@ -131,10 +131,82 @@ def test_pipeline_small_20_steps(small_pair):
     assert st["max_abs"] < bar["max_abs"] * scale and st["rel_rms"] < bar["rel_rms"], st
 
 
+@torch.no_grad()
+def test_pipeline_small_teacher_forced_eps_absolute(small_pair):
+    """Per-step error in ABSOLUTE terms, without the compounding of a non-contractive synthetic model: the engine's CFG-batched
+    UNet call is fed the ORACLE's latent z_i of a 20-step trajectory (teacher forcing) at steps 0, 1, 5, 10, 15, 19 and its
+    eps_c / eps_u are compared with the oracle's at the same z_i.  Seeded weights are not a denoiser (z grows ~14x =
+    sqrt(abar_end / abar_start), for ANY eps uncorrelated with z), so late inputs are far outside the O(1) regime a trained model
+    keeps its latents in; the bar is the north-star atol 1e-2 for fp16 wherever |z| is O(1) (step 0, 1) and 1e-2 x the eps scale
+    relative to step 0 elsewhere; bf16: 6e-2 (8 mantissa bits)."""
+    from oracle.ddim import DDIMOracle
+    from oracle.pipeline import denoise, garment_features
+    p = small_pair
+    steps, gs = 20, 7.5
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(42))
+    pe, ne = g(10, 1, 77, 64, scale=0.5), g(11, 1, 77, 64, scale=0.5)
+    cloth = g(12, 2, 16, 64, scale=0.5); refl = g(13, 1, 4, 16, 16)
+    tr = []
+    sch = DDIMOracle()
+    denoise(p["o_unet"], p["o_ref"], sch, lat, pe, ne, cloth, refl, steps, gs, trace=tr)
+    ts = sch.set_timesteps(steps)
+    zs = [lat] + tr[:-1]                                   # latent going INTO step i
+    sa_o = garment_features(p["o_ref"], refl, cloth)
+    from imagdressing_amd.unet import nchw_to_nhwc8
+    e_ref = p["e_ref"]
+    e_ref.forward_nhwc(nchw_to_nhwc8(refl.cuda(), p["dtype"]), 0, cloth[1:2].cuda().to(p["dtype"]).contiguous())
+    sa_e = {n: pr.cache["hidden_states"] for n, pr in e_ref.attn_processors.items()}
+    mask = torch.tensor([1.0, 0.0], device="cuda")
+    ehs2 = torch.cat([pe, ne]).cuda()
+    base = None
+    for i in (0, 1, 5, 10, 15, 19):
+        z, t = zs[i], int(ts[i])
+        ec = p["o_unet"](z, t, pe, cross_attention_kwargs={"sa_hidden_states": sa_o})
+        eu = p["o_unet"](z, t, ne)
+        got = p["e_unet"](torch.cat([z, z]).cuda(), t, ehs2, cross_attention_kwargs={"sa_hidden_states": sa_e, "sa_batch_mask": mask})[0]
+        ref = torch.cat([ec, eu])
+        st = err_stats(got, ref)
+        st.update(step=i, z_std=z.std().item())
+        record(f"teacher_forced_eps[{p['dtype']}]", st)
+        base = base or st["ref_std"]
+        bar = (1e-2 if p["dtype"] == torch.float16 else 6e-2) * max(1.0, st["ref_std"] / base)
+        assert st["max_abs"] <= bar, st
+
+
 def _sched():
     from imagdressing_amd.scheduler import DDIMScheduler
     return DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                          clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+
+
+@torch.no_grad()
+def test_step_graph_replay_is_bit_identical(small_pair):
+    """``enable_step_graph``: step 1 of the DDIM loop captured once as a HIP graph (timestep + schedule coefficients read from
+    device memory, imd_ddim_params.coefs) and replayed for steps 1..S-1 gives EXACTLY the eager loop's latents (same kernels, same
+    order), at batch 1 -- the reference's literal usage (IMAGDressing_v1_pipeline.py:389) -- and batch 2, twice in a row."""
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+    p = small_pair
+    pe, ne = g(10, 1, 77, 64, scale=0.5), g(11, 1, 77, 64, scale=0.5)
+    cloth = g(12, 2, 16, 64, scale=0.5); refl = g(13, 1, 4, 16, 16)
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           image_encoder=None, ImgProj=lambda h: h, scheduler=_sched(), safety_checker=None, feature_extractor=None)
+    for nimg in (1, 2):
+        lat = torch.stack([torch.randn(4, 16, 16, generator=torch.Generator().manual_seed(42 + i)) for i in range(nimg)])
+
+        def run():
+            return pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=128, height=128,
+                        num_inference_steps=8, guidance_scale=7.5, num_images_per_prompt=nimg, prompt_embeds=pe.cuda(),
+                        negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(), ref_image_latents=refl.cuda(),
+                        latents=lat.cuda(), output_type="latent").images
+        pipe.enable_step_graph(False)
+        eager = run()
+        pipe.enable_step_graph(True)
+        g1 = run()
+        g2 = run()
+        pipe.enable_step_graph(False)
+        assert torch.isfinite(eager).all()
+        assert torch.equal(eager, g1) and torch.equal(eager, g2), (nimg, (eager - g1).abs().max().item())
+    assert getattr(pipe, "_last_step_graph", None) is not None          # the graph path really ran
 
 
 def _traj_bar(dtype):

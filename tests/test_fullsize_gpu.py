@@ -33,11 +33,14 @@ def rnd(seed, *shape, scale=1.0, device="cpu"):
 # ----------------------------------------------------------------------------------------------------------------
 # full-width UNet forward vs the fp32 CPU oracle
 # ----------------------------------------------------------------------------------------------------------------
-@pytest.fixture(scope="module")
-def full_oracle():
-    """(state dict, inputs, fp32 oracle output) of ONE full-width SD1.5 UNet forward at 64x64, batch 1."""
+# latent (rows, cols): 512x512 -> 64x64 (BASELINE configs[1]); the reference scripts' own default, width 512 x height 640 with a
+# 640x512 garment (inference_IMAGdressing.py:182-183) -> 80x64, N = M = 5120 / 1280 / 320 / 80
+@pytest.fixture(scope="module", params=[(64, 64), (80, 64)], ids=["512x512", "512x640"])
+def full_oracle(request):
+    """(state dict, inputs, fp32 oracle output) of ONE full-width SD1.5 UNet forward, batch 1."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    lh, lw = request.param
     from imagdressing_amd import unet as E
     from oracle import processors as OP
     from oracle import sd15
@@ -48,17 +51,17 @@ def full_oracle():
     from tests.harness import hidden_size_of
     o.set_attn_processor({n: (OP.RefSAttn(n, hidden_size_of(n, boc)) if n.endswith("attn1.processor")
                               else OP.CAttn(n, hidden_size_of(n, boc), 768)) for n in o.attn_processors.keys()})
-    x = rnd(1, 1, 4, 64, 64)
+    x = rnd(1, 1, 4, lh, lw)
     ehs = rnd(2, 1, 77, 768, scale=0.5)
-    # garment tokens of every attn1 layer ([1, M_l, C_l], M_l = N_l at 512x512) and seeded to_k_ref / to_v_ref
+    # garment tokens of every attn1 layer ([1, M_l, C_l], M_l = N_l: garment at the generation resolution) and seeded to_k_ref / to_v_ref
     names = [n for n in o.attn_processors.keys() if n.endswith("attn1.processor")]
     from tests.harness import ref_weights
     rw = ref_weights(names, boc, 7)
-    tokens = {320: 4096, 640: 1024, 1280: 256}
+    tokens = {320: lh * lw, 640: lh * lw // 4, 1280: lh * lw // 16}
     sa = {}
     for j, n in enumerate(names):
         c = hidden_size_of(n, boc)
-        m = 64 if n.startswith("mid_block") else tokens[c]
+        m = lh * lw // 64 if n.startswith("mid_block") else tokens[c]
         sa[n] = rnd(100 + j, 1, m, c)
         with torch.no_grad():
             o.attn_processors[n].to_k_ref.weight.copy_(rw[n]["k"]); o.attn_processors[n].to_v_ref.weight.copy_(rw[n]["v"])
@@ -72,7 +75,8 @@ def full_oracle():
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @torch.no_grad()
 def test_full_width_unet_forward_vs_oracle(full_oracle, dtype):
-    """859.5 M-parameter UNet, 64x64 latent: the HIP engine against the fp32 oracle on identical seeded weights.
+    """859.5 M-parameter UNet, 64x64 latent (BASELINE configs[1]) and 80x64 (the reference scripts' default 512x640): the HIP
+    engine against the fp32 oracle on identical seeded weights.
     Bars: fp16 rms 0.5 % and worst element 2e-2 x output std; bf16 rms 2.5 % / 0.12 x std (8 mantissa bits)."""
     from imagdressing_amd import unet as E
     from imagdressing_amd.adapter import attention_processor as AP
@@ -87,7 +91,7 @@ def test_full_width_unet_forward_vs_oracle(full_oracle, dtype):
     assert torch.isfinite(got).all()
     bar = dict(rel_rms=5e-3, max_rel=2e-2) if dtype == torch.float16 else dict(rel_rms=2.5e-2, max_rel=0.12)
     assert st["rel_rms"] < bar["rel_rms"] and st["max_abs"] < bar["max_rel"] * st["ref_std"], st
-    # ---- the COND pass: garment branch on in all 16 hybrid blocks (N = M = 4096 / 1024 / 256 / 64), and the pipeline's
+    # ---- the COND pass: garment branch on in all 16 hybrid blocks (N = M = 4096 / 1024 / 256 / 64 or 5120 / 1280 / 320 / 80), and the pipeline's
     # CFG layout -- [cond; uncond] rows in one call, garment switched per row (sa_batch_mask) -- against the two oracle passes
     for n, p in e.attn_processors.items():
         if n.endswith("attn1.processor"):

@@ -501,6 +501,50 @@ def test_attention(ops, D, B, N, L1, L2, dt):
     assert_close(out, ref, atol=1e-2, rtol=1e-2, what=f"attention D={D}")
 
 
+@pytest.mark.parametrize("variant", [10, 11, 9, 7])
+@pytest.mark.parametrize("pad_one", [True, False])
+@pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (530, 700, 0), (512, 1000, 520)])
+@DTS
+def test_attention_d40_kernel_variants(ops, N, L1, L2, pad_one, variant, dt):
+    """The software-pipelined head-dim-40 kernel (attention_d40.hip; N >= 512) in every shipped variant -- 10: head-dim rows
+    32..40 of P.V on v_mfma_f32_16x16x32 (default), 9: the round-2 kernel, 11 / 7: the same two with register staging --
+    with and without the caller's K pad-column guarantee (LDS-DMA vs register staging), ragged key counts, a second key
+    set on one of two batch rows, and a late spike that takes the exact (redo) path and raises the deferred maximum."""
+    D, H, B = 40, 8, 2
+    Cc = H * D
+    dpk, dpv = ops.attn_padded_dims(D)
+    q = rnd(1, B, N, Cc).to(dt)
+    k1 = rnd(2, B, L1, Cc).to(dt); v1 = rnd(3, B, L1, Cc).to(dt)
+    k1[:, L1 - 90] = q[:, 7] * 3.0                       # a key far above the rest late in the sequence
+    scale = D ** -0.5 * math.log2(math.e)
+
+    def kbuf(x):
+        h = to_heads(x, H, dpk, dt=dt)
+        if pad_one:
+            h[..., D] = 1.0
+        return dev(h)
+    out = torch.empty(B, N, Cc, dtype=dt, device="cuda")
+    ref = ref_attn(q, k1, v1, H)
+    kw = {}
+    if L2:
+        k2 = rnd(4, 1, L2, Cc).to(dt); v2 = rnd(5, 1, L2, Cc).to(dt)
+        k2[:, L2 - 40] = q[1, 300] * 3.0
+        s2 = torch.tensor([0.9, 0.0])
+        r2 = ref_attn(q, k2.expand(B, -1, -1), v2.expand(B, -1, -1), H)
+        ref = ref.to(dt).float() + s2[:, None, None] * r2
+        kw = dict(k2=kbuf(k2), v2t=dev(to_heads_t(v2, H, dpv, ops.pad64(L2), dt=dt)), scale2=dev(s2), L2=L2, L2P=ops.pad64(L2),
+                  kv2_bdiv=B)
+    lib = ops.L.load()
+    ops.L.check(lib.imd_set_tuning(0, variant))
+    try:
+        ops.attention(dev(to_heads(q, H, dpk, scale, dt=dt)), kbuf(k1), dev(to_heads_t(v1, H, dpv, ops.pad64(L1), dt=dt)), out,
+                      B=B, H=H, N=N, D=D, L1=L1, L1P=ops.pad64(L1), k_pad_one=pad_one, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.L.check(lib.imd_set_tuning(0, 10))
+    assert_close(out, ref, atol=1e-2 if dt == torch.float16 else 2e-2, rtol=2e-2, what=f"attention d40 variant {variant}")
+
+
 @DTS
 def test_attention_shared_kv_batch_div(ops, dt):
     """text K/V computed once per prompt and shared by groups of batch rows (kv batch = b // bdiv)."""

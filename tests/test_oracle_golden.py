@@ -76,6 +76,20 @@ def test_hybrid_restatement_full_size(golden_full, name):
         assert c["out_uncond"].abs().max() > 2.0
 
 
+@pytest.mark.parametrize("name", ["hybrid_d40_n5120", "hybrid_d80_n1280", "hybrid_d160_n320", "hybrid_d160_n80"])
+def test_hybrid_restatement_default_geometry(golden_geometry, name):
+    """The restatement against the reference source at the four UNet levels of the scripts' own default geometry
+    (512 x 640 image, 640 x 512 garment: N = M = 5120 / 1280 / 320 / 80; inference_IMAGdressing.py:182-183)."""
+    c = golden_geometry[name]
+    i = hybrid_inputs(c)
+    args = (i["x"], i["wq"], i["wk"], i["wv"], i["wo"], i["bo"], c["heads"])
+    cond = P.hybrid_self_attention(*args, ref=i["ref"], wk_ref=i["wk_ref"], wv_ref=i["wv_ref"], scale=c["scale"])
+    unc = P.hybrid_self_attention(*args)
+    _close(cond[:, c["rows"]], c["out_cond"])
+    _close(unc[:, c["rows"]], c["out_uncond"])
+    assert (c["out_cond"] - c["out_uncond"]).abs().max() > 1e-2
+
+
 @pytest.mark.parametrize("name", ["cache_d40", "cache_d80_cross"])
 def test_cache_restatement_real_dims(golden_full, name):
     c = golden_full[name]

@@ -142,6 +142,33 @@ def test_hybrid_processor_benchmarked_shape_vs_reference_golden(golden_full, nam
 
 
 @DT
+@pytest.mark.parametrize("name", ["hybrid_d40_n5120", "hybrid_d80_n1280", "hybrid_d160_n320", "hybrid_d160_n80"])
+@torch.no_grad()
+def test_hybrid_processor_default_geometry_vs_reference_golden(golden_geometry, name, dt):
+    """The reference scripts' OWN default geometry -- width 512 x height 640, garment 640 x 512 (inference_IMAGdressing.py:182-183;
+    latent 80 x 64): N = M = 5120 at level 0 (the d = 40 kernel), 1280 / 320 / 80 at the deeper levels -- against outputs of the
+    REFERENCE source (adapter/attention_processor.py:531-627), in the CFG layout of the pipeline as well."""
+    from imagdressing_amd.adapter import attention_processor as A
+    c = golden_geometry[name]
+    i = hybrid_inputs(c)
+    attn = make_attn(i, c["heads"], dt)
+    pname = "blk.attn1.processor"
+    proc = A.RefSAttnProcessor2_0(pname, c["C"], scale=c["scale"])
+    proc.to_k_ref.weight.copy_(i["wk_ref"]); proc.to_v_ref.weight.copy_(i["wv_ref"])
+    attn.set_processor(proc)
+    x = i["x"].cuda().to(dt)
+    ref = i["ref"].cuda()
+    rows = c["rows"]
+    cond = attn(x, sa_hidden_states={pname: ref})
+    check_rows(cond[:, rows], c["out_cond"], dt, f"{name} cond")
+    unc = attn(x)
+    check_rows(unc[:, rows], c["out_uncond"], dt, f"{name} uncond")
+    both = attn(torch.cat([x, x]), sa_hidden_states={pname: ref}, sa_batch_mask=torch.tensor([1.0, 0.0], device="cuda"))
+    check_rows(both[0:1, rows], c["out_cond"], dt, f"{name} CFG row 0")
+    check_rows(both[1:2, rows], c["out_uncond"], dt, f"{name} CFG row 1")
+
+
+@DT
 @pytest.mark.parametrize("name", ["cache_d40", "cache_d80_cross"])
 @torch.no_grad()
 def test_cache_processor_vs_reference_golden(golden_full, name, dt):

@@ -44,7 +44,7 @@ def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False, fp8=False):
     # algorithmic HBM bytes: Q,K read + V^T read (D rows) per row, garment K/V once per (cond row, head) from L2/HBM, O written
     alg_bytes = 2 * (B * H * N * dpk * 2) + B * H * D * N * 2 + H * (M * dpk + D * M) * 2 + B * N * C * 2
     extra = {}
-    if qw in (21, 22):
+    if qw in (31, 32):
         out.zero_(); go(); torch.cuda.synchronize()
         c = out.view(torch.int64).flatten()[:6].tolist()
         waves, steps = max(c[5], 1), max(c[4], 1)
@@ -58,7 +58,7 @@ if __name__ == "__main__":
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only-l0", action="store_true")
     ap.add_argument("--variants", default="", help="comma list of knob-0 values to A/B on the level-0 shape")
-    ap.add_argument("--cycles", action="store_true", help="variants 21 / 22: print the in-kernel s_memtime counters (per wave and 32-key step)")
+    ap.add_argument("--cycles", action="store_true", help="variants 31 / 32 (-DIMD_ABLATIONS builds): print the in-kernel s_memtime counters (per wave and 32-key step)")
     ap.add_argument("--fp8", action="store_true", help="also time imd_attention_fp8 (operands quantised outside the timed region)")
     ap.add_argument("--N", type=int, default=4096, help="tokens of the level-0 shape (6912 = the 768x576 configuration)")
     ap.add_argument("--zero", action="store_true", help="all-zero Q/K/V: same instruction stream, far fewer toggling bits (clock / power probe)")
@@ -77,4 +77,4 @@ if __name__ == "__main__":
             print(json.dumps(dict(run(D, N, M, Bi, a.iters, dt, qw, xcd, a.zero), zero=a.zero)), flush=True)
         if a.fp8:
             print(json.dumps(dict(run(40, a.N, a.N, 4, a.iters, dt, None, 1, a.zero, fp8=True), fp8=True)), flush=True)
-    ops.L.load().imd_set_tuning(0, 1); ops.L.load().imd_set_tuning(1, 1)
+    ops.L.load().imd_set_tuning(0, 10); ops.L.load().imd_set_tuning(1, 1)
