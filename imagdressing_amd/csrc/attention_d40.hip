@@ -79,12 +79,20 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
 //   16: no global loads / LDS stores in the loop   32: no P.V MFMAs   64: no QK^T MFMAs   256: one LDS fragment read per step
 //   512: 100 KB of LDS per workgroup (one workgroup = one wave per SIMD)   2048: no packed-max / overflow test
 //   4096: s_memtime instrumentation (per-phase cycle sums of every wave's loop, added into the first words of `out`)
+//   32768 (WG512): 8 waves = 512 queries per workgroup (one workgroup per CU instead of two): a staged K / V^T unit serves twice
+//   the queries, i.e. every wave issues 2 instead of 3 LDS-DMA pieces per 64 keys (the DMA issue sequence costs ~15 % of the
+//   4-wave kernel: profiles/r3b_attn_ablations.jsonl) and there is one barrier domain per CU.  LDS-DMA staging only.
 template <bool F16, int THR, int VAR>
-__global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
+__global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(const AttnParams p) {
     using E = El<F16>;
     constexpr bool DMA = (VAR & 128) != 0;
     constexpr bool TAIL = (VAR & 8192) != 0;
-    constexpr int PARKB = TAIL ? PARK_T : PARK;
+    constexpr int NW = (VAR & 32768) ? 8 : 4;              // waves per workgroup
+    constexpr int NT = NW * 64;
+    constexpr int NPIECE = (11 + NW - 1) / NW;             // LDS-DMA pieces every wave issues per unit (dummies included)
+    static_assert(NW == 4 || DMA, "the 8-wave workgroup exists for the LDS-DMA staging only");
+    constexpr int PARKW = (TAIL ? PARK_T : PARK) / 4;      // phase-0 park bytes per wave
+    constexpr int PARKB = NW * PARKW;
     constexpr int BUFB = DMA ? BUF_D : BUF, VBY = DMA ? VBYTES_D : VBYTES;
     constexpr float OFFS_THR = (float)THR;                 // deferred maximum: P <= 2^THR (base-2 units)
     constexpr int QPAD_T = D / 16, QPAD_HI = (D % 16) / 8;  // Q fragment / half-wave holding pad slot 40 (element 0 of the fragment)
@@ -111,13 +119,13 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         b = (int)((w / gx) % gz);
         h = (int)(w / (gx * gz));
     }
-    const int q0 = (wx * 4 + wave) * 64;
+    const int q0 = (wx * NW + wave) * 64;
 
     // V^T row 40 (all ones) of both buffers: written once, never restaged
     {
         constexpr int PADV = (DMA ? VSTR_D : VSTR) / 16;
         const uint32_t one2 = E::pack2(1.0f, 1.0f);
-        for (int v = tid; v < (DMA ? NRING : 2) * PADV; v += 256)
+        for (int v = tid; v < (DMA ? NRING : 2) * PADV; v += NT)
             *reinterpret_cast<uint4*>(smem + (v / PADV) * BUFB + D * (DMA ? VSTR_D : VSTR) + (v % PADV) * 16) = make_uint4(one2, one2, one2, one2);
     }
 
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         for (int sec = 0; sec < 2; ++sec)
             tfd[sec] = DMA ? (32 + r) * VSTR_D + (((4 * sec + pc0) ^ tsw) * 16) : (32 + r) * VSTR + (4 * sec + pc0) * 16;
     }
-    char* park = smem + (DMA ? NRING : 2) * BUFB + wave * (PARKB / 4) + lane * 16;
+    char* park = smem + (DMA ? NRING : 2) * BUFB + wave * PARKW + lane * 16;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -217,11 +225,11 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const v4i_t ds_k = raw_rsrc(kbase, (uint32_t)L * DPK * 2), ds_v = raw_rsrc(vbase, (uint32_t)D * LP * 2);
         const uint32_t smem_base = (uint32_t)(uintptr_t)smem;          // LDS byte address of the dynamic region
-        int dsrc[3];                 // byte offset of this lane's piece inside K / V^T for unit 0
-        bool dneg[3];                // V^T pieces that lie before column 0 in unit 0 (K rows before row 0 in unit -1)
+        int dsrc[NPIECE];            // byte offset of this lane's piece inside K / V^T for unit 0
+        bool dneg[NPIECE];           // V^T pieces that lie before column 0 in unit 0 (K rows before row 0 in unit -1)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int qi = wv + 4 * i;
+        for (int i = 0; i < NPIECE; ++i) {
+            const int qi = wv + NW * i;
             if (qi >= 11) {
                 dsrc[i] = 0; dneg[i] = true;
             } else if (qi < 6) {
@@ -238,14 +246,15 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         }
         auto dma_unit = [&](int u, int bufi) {     // u >= 1 inside the loop: no range logic at all (rows / columns past the end read 0)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {      // EVERY wave issues exactly 3 pieces (the counted vmcnt relies on it)
-                const int qi = wv + 4 * i;
+            for (int i = 0; i < NPIECE; ++i) {      // EVERY wave issues exactly NPIECE pieces (the counted vmcnt relies on it)
+                const int qi = wv + NW * i;
                 const bool isk = qi < 6, none = qi >= 11;
                 const bool bad = none || (isk ? (u < 0 && dneg[i]) : (u <= 0 && (u < 0 || dneg[i])));
                 const uint32_t off = bad ? OOB : (uint32_t)(dsrc[i] + u * (isk ? KT * DPK * 2 : KT * 2));
                 const uint32_t dst = none ? smem_base + NRING * BUF_D + PARKB
                                           : smem_base + bufi * BUF_D + (isk ? VBYTES_D + 1024 * qi : 1024 * (qi - 6));
-                dma16(isk ? ds_k : ds_v, dst, off);
+                if ((VAR & 65536) && u >= 2) dma16_nonop(isk ? ds_k : ds_v, dst, off);      // (loop pieces: SGPR operands are loop-carried SALU values)
+                else dma16(isk ? ds_k : ds_v, dst, off);
             }
         };
 
@@ -262,7 +271,11 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         // then the exp2 of pair i+1, the pack of pair i and every other slot a max3 -- and pinned with sched_barrier, with
         // the LDS fragment reads issued two fragments (four MFMAs) ahead.  Otherwise the three streams are emitted one
         // after the other and hipcc's scheduler decides.
-        uint4 fr[3];                 // LDS fragment ring: fragment f of a step lives in fr[(R0 + f) % 3]
+        // TAIL schedule: fragment reads run PD fragments (2 PD MFMA slots) ahead of their use, ring of PD + 1 registers
+        // (VAR & 131072: PD = 3, VAR & 262144: PD = 4; default 2)
+        constexpr int PD = (VAR & 262144) ? 4 : (VAR & 131072) ? 3 : 2;
+        constexpr int NFR = TAIL ? PD + 1 : 3;
+        uint4 fr[NFR];               // LDS fragment ring: fragment f of a step lives in fr[(R0 + f) % 3]  (TAIL: (R0T + f) % (PD + 1))
         auto step = [&](const char* Vs, auto second_c, int j, f32x16 (&sc)[2], f32x16 (&sn)[2], uint4 (&pc)[2][2],
                         uint4 (&pp)[2][2]) {
             constexpr bool SECOND = decltype(second_c)::value;        // second step of a unit: K block kb = 1, V^T groups 2, 3
@@ -302,14 +315,16 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                 // 10..13 the four 16x16x32 tail MFMAs (query block, 16-query half) on P swapped in place during slots 4..11.
                 auto fragT = [&](int sq, int sec) -> uint4 {
                     const int g0 = sec ? 2 : 0;
+                    if ((VAR & 256) && sq > 0) sq = 0;
                     if (sq < 2) return DMA ? *reinterpret_cast<const uint4*>(Vs + vfd[g0 + sq])
                                            : *reinterpret_cast<const uint4*>(Vs + vfrag + (g0 + sq) * 32);
                     if (sq < 5) return DMA ? *reinterpret_cast<const uint4*>(Ks + sec * 32 * KSTR_D + kfd[sq - 2])
                                            : *reinterpret_cast<const uint4*>(Ks + sec * 32 * KSTR + kfrag + (sq - 2) * 32);
                     return *reinterpret_cast<const uint4*>(Vs + tfd[sec]);
                 };
+                constexpr int R0T = SECOND ? (6 % NFR) : 0;       // ring slot of this step's fragment 0 (6 fragments per step)
                 auto mmaT = [&](int i) {
-                    const uint4& fa = fr[(i < 10 ? (i >> 1) : 5) % 3];
+                    const uint4& fa = fr[(R0T + (i < 10 ? (i >> 1) : 5)) % NFR];
                     if (i < 4) o[i & 1][0] = E::mfma(fa, pp[i & 1][i >> 1], o[i & 1][0]);
                     else if (i < 10) sn[i & 1] = E::mfma(fa, qf[i & 1][(i >> 1) - 2], i < 6 ? zero16 : sn[i & 1]);
                     else ot[(i - 10) >> 1][i & 1] = E::mfma16(fa, pp[(i - 10) >> 1][i & 1], ot[(i - 10) >> 1][i & 1]);
@@ -322,30 +337,30 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
                     const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
                     x = r[0]; y = r[1];
                 };
-                if (!SECOND) {       // (the second step's first two fragments were read during the first step's last slots)
-                    fr[0] = fragT(0, 0);
-                    fr[1] = fragT(1, 0);
+                if (!SECOND) {       // (the second step's first PD fragments were read during the first step's last slots)
+#pragma unroll
+                    for (int f = 0; f < PD; ++f) fr[f] = fragT(f, 0);
                 }
                 exp_pair(0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 14; ++i) {
-                    if ((i & 1) == 0) {
-                        const int f2 = (i >> 1) + 2;
-                        if (f2 <= 5) fr[f2 % 3] = fragT(f2, SECOND ? 1 : 0);
-                        else if (!SECOND && f2 <= 7) fr[f2 - 6] = fragT(f2 - 6, 1);     // next step's fragments 0 and 1 (slots 8, 10)
+                    if ((i & 1) == 0 && i <= 10) {      // slot pair of fragment i / 2: read fragment i / 2 + PD (this step's, else the next step's)
+                        const int f2 = (i >> 1) + PD;
+                        if (f2 <= 5) fr[(R0T + f2) % NFR] = fragT(f2, SECOND ? 1 : 0);
+                        else if (!SECOND && f2 - 6 < PD) fr[(R0T + f2) % NFR] = fragT(f2 - 6, 1);
                     }
                     mmaT(i);
                     exp_pair(i + 1);
                     cvt_pair(i);
-                    if (i & 1) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
+                    if ((i & 1) && !(VAR & 2048)) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
                     if (i >= 4 && i < 12) swapT(i - 4);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 exp_pair(15);
                 cvt_pair(14);
                 cvt_pair(15);
-                mq[0] = pk_max3(mq[0], word(14), word(15));
+                if (!(VAR & 2048)) mq[0] = pk_max3(mq[0], word(14), word(15));
             } else if (VAR & 1) {
                 if (!SECOND) {       // (the second step's first two fragments were read during the first step's last slots)
                     fr[0] = frag(0, KB, G0);
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void attn40_kernel(const AttnParams p) {
         // (register staging keeps the simpler form: NU full iterations, past-the-end blocks masked to P = 0 on the exact path)
         const int NUF = DMA ? (J >> 1) : NU;
         auto iteration_sync = [&]() {
-            if (DMA) dma_wait_keep3();                              // this wave's pieces of unit u + 1 have landed (u + 2 stays in flight) ...
+            if (DMA) { if (NPIECE == 3) dma_wait_keep3(); else dma_wait_keep2(); }   // this wave's pieces of unit u + 1 have landed (u + 2 stays in flight) ...
             if (!(VAR & 8)) __syncthreads();                        // ... and so have everybody else's
         };
         int ring = 0;                                               // u % NRING
@@ -637,15 +652,16 @@ template <bool F16, int THR, int VAR>
 int launch_attn40(const AttnParams& p, hipStream_t s) {
     static bool attr_set = false;
     auto kern = attn40_kernel<F16, THR, VAR>;
-    constexpr int PARKB = (VAR & 8192) ? PARK_T : PARK;
+    constexpr int NW = (VAR & 32768) ? 8 : 4;
+    constexpr int PARKB = NW * ((VAR & 8192) ? PARK_T : PARK) / 4;
     constexpr int LDS_BYTES = (VAR & 512) ? 100 * 1024 : (VAR & 128) ? NRING * BUF_D + PARKB + 1024 : 2 * BUF + PARKB;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return imd_set_error("attention(d=40): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid((p.N + 255) / 256, p.H, p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, s, p);
+    dim3 grid((p.N + NW * 64 - 1) / (NW * 64), p.H, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), LDS_BYTES, s, p);
     return imd_check_launch("attention(d=40)");
 }
 
@@ -666,6 +682,21 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
             if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128>(p, s) : launch_attn40<false, 8, 1 | 128>(p, s);
             return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
         case 7: return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
+        case 12:            // 10 with 8-wave (512-query) workgroups
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 32768>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 32768>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 13:            // 12 without the five leading wait states of the loop's DMA pieces
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 32768 | 65536>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 32768 | 65536>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 14:            // 10 without them
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 65536>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 65536>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 15:            // 10 with fragment reads three fragments ahead
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 131072>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 131072>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 16:            // ... four fragments ahead
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 262144>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 262144>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
         case 11:            // the 16x16x32 tail with register staging always
             return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
 #ifdef IMD_ABLATIONS
@@ -691,6 +722,16 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
         case 37: return launch_attn40<false, 8, 1 | 128 | 512 | 32 | 64>(p, s);        // 2 MFMAs per step
         case 38: return launch_attn40<false, 8, 1 | 128 | 512 | 4 | 16 | 2048>(p, s);  // MFMAs, packs and fragment reads only
         case 39: return launch_attn40<false, 8, 1 | 128 | 512 | 8>(p, s);              // no barrier
+        // ablations of the default kernel (variant 10: 16x16x32 tail + LDS-DMA staging)
+        case 40: return launch_attn40<false, 8, 1 | 128 | 8192 | 2048>(p, s);          // no packed-max / overflow test
+        case 41: return launch_attn40<false, 8, 1 | 128 | 8192 | 8>(p, s);             // no loop barrier
+        case 42: return launch_attn40<false, 8, 1 | 128 | 8192 | 16>(p, s);            // no staging in the loop
+        case 43: return launch_attn40<false, 8, 1 | 128 | 8192 | 4>(p, s);             // exp2 -> move
+        case 44: return launch_attn40<false, 8, 1 | 128 | 8192 | 256>(p, s);           // one LDS fragment read per step
+        case 45: return launch_attn40<false, 8, 1 | 128 | 8192 | 8 | 16>(p, s);        // no barrier, no staging
+        case 46: return launch_attn40<false, 8, 1 | 128 | 8192 | 8 | 16 | 2048>(p, s); // ... and no overflow test
+        case 47: return launch_attn40<false, 8, 1 | 128 | 8192 | 8 | 16 | 2048 | 256>(p, s);   // ... and one fragment read
+        case 48: return launch_attn40<false, 8, 1 | 128 | 8192 | 512>(p, s);           // one workgroup per CU
 #endif
         case 10:
         default:

@@ -19,7 +19,15 @@ __device__ __forceinline__ void dma16(const v4i_t& rsrc, uint32_t lds_addr, uint
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
 }
+// The same piece for steady-state loops whose descriptor and LDS address were produced by SALU instructions well ahead: without the
+// five leading wait states (they cover a descriptor SGPR written by a VALU -- v_readfirstlane -- immediately before)
+__device__ __forceinline__ void dma16_nonop(const v4i_t& rsrc, uint32_t lds_addr, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void dma_wait_keep2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }   // all but the 2 youngest pieces
 __device__ __forceinline__ void dma_wait_keep3() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }   // all but the 3 youngest pieces
 __device__ __forceinline__ void dma_wait_keep5() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }   // all but the 5 youngest pieces
 __device__ __forceinline__ v4i_t raw_rsrc(const void* base, uint32_t bytes) {      // stride 0, raw addressing, wave-uniform by construction

@@ -20,14 +20,14 @@ from imagdressing_amd import unet as E
 from imagdressing_amd.adapter import attention_processor as AP
 
 
-def build(config: int, dev, dt, batch=None, steps=6):
+def build(config: int, dev, dt, batch=None, steps=6, width=512, height=512):
     g = torch.Generator().manual_seed(2)
     rn = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale        # noqa: E731
-    if config == 1:
+    if config == 1:          # (width / height: also the reference scripts' default geometry 512 x 640 and batch 1, for the tuning table)
         batch = batch or 4
         pipe = bench.build_pipeline(dev, dt, 0)
-        inp = bench.synthetic_inputs(argparse.Namespace(batch=batch, res=512), dev, dt, 0, 1)
-        kw = dict(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=512, height=512,
+        inp = bench.synthetic_inputs(width, height, batch, dev, dt, 0, 1)
+        kw = dict(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=width, height=height,
                   num_inference_steps=steps, guidance_scale=7.5, num_images_per_prompt=batch, output_type="latent", **inp)
         return pipe, kw
     base = bench.build_pipeline(dev, dt, 0)

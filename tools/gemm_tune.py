@@ -18,7 +18,7 @@ def collect_shapes(args, dt):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import configs
     dev = torch.device("cuda", 0)
-    pipe, kw = configs.build(args.config, dev, dt, args.batch or None, steps=1)
+    pipe, kw = configs.build(args.config, dev, dt, args.batch or None, steps=1, width=args.width, height=args.height)
     ops.GEMM_TRACE = []
     pipe(**kw)
     torch.cuda.synchronize()
@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--config", type=int, default=1, help="BASELINE configuration whose shapes are tuned: 1 (bench line), 3 (IPA + "
                     "ControlNet, batch 8), 5 (768x576 inpainting + ControlNet, 4 images); see tools/configs.py")
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--width", type=int, default=512, help="config 1 only: generated width (the reference scripts' default geometry is 512 x 640)")
+    ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--merge", action="store_true", help="start from the shipped table and add / overwrite only the traced shapes")
     ap.add_argument("--skip-known", action="store_true", help="with --merge: leave shapes that the shipped table already holds alone")
     ap.add_argument("--quick", action="store_true", help="one repeat, K splits {1, 2, 4}")

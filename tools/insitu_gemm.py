@@ -12,7 +12,7 @@ def dump(path, steps):
     from imagdressing_amd import ops
     dev = torch.device("cuda", 0)
     pipe = bench.build_pipeline(dev, torch.bfloat16, 0)
-    inp = bench.synthetic_inputs(argparse.Namespace(batch=4, res=512), dev, torch.bfloat16, 0, 1)
+    inp = bench.synthetic_inputs(512, 512, 4, dev, torch.bfloat16, 0, 1)
 
     def run():
         return pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=512, height=512,

@@ -1,0 +1,55 @@
+"""Sustained run of one kernel configuration while sampling the board's power and shader clock with rocm-smi (is the kernel
+power- / clock-limited?).  python tools/power_probe.py --variant 10 [--zero] [--seconds 4]"""
+import argparse, json, math, os, subprocess, sys, threading, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from imagdressing_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--variant", type=int, default=10)
+ap.add_argument("--zero", action="store_true")
+ap.add_argument("--seconds", type=float, default=4.0)
+ap.add_argument("--what", default="attn", choices=["attn", "idle"])
+a = ap.parse_args()
+dt = torch.bfloat16
+D, N, H, Bimg = 40, 4096, 8, 4
+B = 2 * Bimg
+dpk, dpv = ops.attn_padded_dims(D)
+g = torch.Generator(device="cuda").manual_seed(0)
+def r(*s): return torch.randn(*s, generator=g, device="cuda").to(dt) * (0.0 if a.zero else 1.0)
+q = torch.zeros(B, H, N, dpk, dtype=dt, device="cuda"); q[..., :D] = r(B, H, N, D) * (D ** -0.5 * math.log2(math.e))
+k = ops.k_buffer((B, H, N, dpk), D, dt, "cuda"); k[..., :D] = r(B, H, N, D)
+vt = torch.zeros(B, H, dpv, N, dtype=dt, device="cuda"); vt[:, :, :D, :N] = r(B, H, D, N)
+kr = ops.k_buffer((1, H, N, dpk), D, dt, "cuda"); kr[..., :D] = r(1, H, N, D)
+vr = torch.zeros(1, H, dpv, N, dtype=dt, device="cuda"); vr[:, :, :D, :N] = r(1, H, D, N)
+s2 = torch.cat([torch.ones(Bimg), torch.zeros(Bimg)]).cuda()
+out = torch.empty(B, N, H * D, dtype=dt, device="cuda")
+ops.L.check(ops.L.load().imd_set_tuning(0, a.variant))
+def go():
+    ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=N, k2=kr, v2t=vr, scale2=s2, L2=N, L2P=N, kv2_bdiv=B, k_pad_one=True)
+samples, stop = [], False
+def sampler():
+    while not stop:
+        try:
+            o = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
+            j = json.loads(o)
+            c = j.get("card0", {})
+            samples.append({k2: v for k2, v in c.items() if "ower" in k2 or "sclk" in k2.lower()})
+        except Exception as e:
+            samples.append({"err": str(e)[:80]})
+        time.sleep(0.05)
+th = threading.Thread(target=sampler); th.start()
+for _ in range(5): go()
+torch.cuda.synchronize()
+t0 = time.time(); n = 0
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+while time.time() - t0 < a.seconds:
+    if a.what == "attn":
+        for _ in range(50): go()
+        n += 50
+    torch.cuda.synchronize()
+e1.record(); torch.cuda.synchronize()
+stop = True; th.join()
+us = e0.elapsed_time(e1) * 1e3 / max(n, 1)
+print(json.dumps(dict(variant=a.variant, zero=a.zero, what=a.what, launches=n, us_per_launch=round(us, 1), samples=samples[len(samples)//3:][:12])))
