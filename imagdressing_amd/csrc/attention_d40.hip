@@ -672,7 +672,9 @@ int launch_attn40(const AttnParams& p, hipStream_t s) {
 //          (imd_attn_params.k_pad_one), through registers otherwise;
 //          9 = round-2 default (P.V as two 32x32x16 row blocks), same staging rule;  7 = 9 with register staging always;
 //          6 = 7 with the compiler's own interleave;  8 = 7 with the deferred-maximum bound 2^12 instead of 2^8
-//          20..39 (only when built with -DIMD_ABLATIONS): timing ablations with WRONG results (tools/attn_bench.py)
+//          20..49 (only when built with -DIMD_ABLATIONS): timing ablations with WRONG results (tools/attn_bench.py);
+//          50..54 (same builds): correct variants measured no faster -- 8-wave workgroups, DMA pieces without their leading wait
+//          states, LDS fragment reads 3 / 4 fragments ahead
 int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (variant) {
@@ -682,21 +684,6 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
             if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128>(p, s) : launch_attn40<false, 8, 1 | 128>(p, s);
             return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
         case 7: return h ? launch_attn40<true, 8, 1>(p, s) : launch_attn40<false, 8, 1>(p, s);
-        case 12:            // 10 with 8-wave (512-query) workgroups
-            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 32768>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 32768>(p, s);
-            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
-        case 13:            // 12 without the five leading wait states of the loop's DMA pieces
-            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 32768 | 65536>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 32768 | 65536>(p, s);
-            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
-        case 14:            // 10 without them
-            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 65536>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 65536>(p, s);
-            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
-        case 15:            // 10 with fragment reads three fragments ahead
-            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 131072>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 131072>(p, s);
-            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
-        case 16:            // ... four fragments ahead
-            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 262144>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 262144>(p, s);
-            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
         case 11:            // the 16x16x32 tail with register staging always
             return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
 #ifdef IMD_ABLATIONS
@@ -732,6 +719,22 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
         case 46: return launch_attn40<false, 8, 1 | 128 | 8192 | 8 | 16 | 2048>(p, s); // ... and no overflow test
         case 47: return launch_attn40<false, 8, 1 | 128 | 8192 | 8 | 16 | 2048 | 256>(p, s);   // ... and one fragment read
         case 48: return launch_attn40<false, 8, 1 | 128 | 8192 | 512>(p, s);           // one workgroup per CU
+        // round-3 variants that compute CORRECT results and measured no faster than 10 (profiles/r3c_*, r3d_*): the kernel is power-capped
+        case 50:            // 10 with 8-wave (512-query) workgroups
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 32768>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 32768>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 51:            // 50 without the five leading wait states of the loop's DMA pieces
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 32768 | 65536>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 32768 | 65536>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 52:            // 10 without them
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 65536>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 65536>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 53:            // 10 with fragment reads three fragments ahead
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 131072>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 131072>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+        case 54:            // ... four fragments ahead
+            if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 262144>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 262144>(p, s);
+            return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
 #endif
         case 10:
         default:

@@ -88,13 +88,13 @@ int imd_set_tuning(int knob, int value) {
     switch (knob) {
         case 0:
 #ifdef IMD_ABLATIONS
-            IMD_REQUIRE(value >= 1 && value <= 49, "set_tuning: attention variant for head dim 40 must be 1..49 (20..49: timing ablations, WRONG results)");
+            IMD_REQUIRE(value >= 1 && value <= 54, "set_tuning: attention variant for head dim 40 must be 1..54 (20..49: timing ablations, WRONG results; 50..54: correct but no faster)");
 #else
-            IMD_REQUIRE(value >= 1 && value <= 16, "set_tuning: attention variant for head dim 40 must be 1..16 (the timing ablations 20..39 exist only in -DIMD_ABLATIONS builds)");
+            IMD_REQUIRE(value >= 1 && value <= 11, "set_tuning: attention variant for head dim 40 must be 1..11 (the timing ablations 20..49 and the measured no-gain variants 50..54 exist only in -DIMD_ABLATIONS builds)");
 #endif
             g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
-        case 2: g_gemm_flags = value & 1023; return 0;   // (bit 8: row_linear staged epilogue, bit 9: halo-patch conv with LDS-staged weights; A/B only)
+        case 2: g_gemm_flags = value & 511; return 0;   // (bit 8: row_linear staged epilogue, A/B only)
         default: return imd_set_error("set_tuning: unknown knob %d", knob);
     }
 }

@@ -43,12 +43,7 @@ __device__ constexpr unsigned char kColPix[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 
                                                   30, 31, 16, 17, 22, 23, 24, 25, 26, 27, 28, 29, 18, 19, 20, 21};
 constexpr int W_VECS = BN * (CK / 8) / 256;             // 2
 
-// WREG (round 3): the weight tile never touches LDS.  A wave's MFMA A-operand fragments -- 64 output channels x 32 input channels of
-// one tap = four 16-byte loads per lane, each row's 64 bytes contiguous in the [Cout][ky][kx][Cin] weight layout -- go from
-// global memory (L2) straight into registers, two taps ahead in a ring of three register stages.  With the weights out of LDS the
-// per-tap workgroup barrier disappears (one barrier per 32-channel chunk = per 72 MFMAs of a wave instead of per 8), the LDS
-// fragment reads per MFMA halve (activation fragments only) and the VGPR -> LDS weight stores are gone.
-template <bool F16, bool WREG>
+template <bool F16>
 __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmParams p) {
     using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,58 +175,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     // the last channel tile of N = 320 / 960 ... is half empty: waves that own no valid channel skip the matrix work
     const bool wave_live = n0 + wn0 < p.N;
 
-    if constexpr (WREG) {
-        uint32_t wrow[2];            // byte offset of this lane's weight row (+ its half of a 16-channel slice) at tap 0, chunk 0
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int n = n0 + wn0 + a * 32 + col;
-            wrow[a] = (n < p.N) ? (uint32_t)(((size_t)n * p.K + hi * 8) * 2) : OOB;
-        }
-        uint4 wq[3][2][2];           // [stage][32-channel block a][16-deep slice kk]
-        auto load_wq = [&](uint4 (&w)[2][2], int it) {
-            const int c = c_begin + it / 9, t = it - (it / 9) * 9;
-            const uint32_t koff = (uint32_t)((t * p.Cin + c * CK) * 2);
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-                    w[a][kk] = buf_load16_nl1(rs_w, (wrow[a] != OOB && it < total && wave_live) ? wrow[a] + koff + (uint32_t)(kk * 32) : OOB);
-        };
-        if (total > 0) {
-            load_patch(c_begin);
-            load_wq(wq[0], 0);
-            load_wq(wq[1], 1);
-            store_patch(0, c_begin);
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int cc = 0; cc < c_end - c_begin; ++cc) {
-            const int c = c_begin + cc;
-            const int ab = cc & 1;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {                  // (9 taps = 3 turns of the stage ring: stage indices are compile-time)
-                if (t == 0) load_patch(c + 1);             // (before the weight prefetch: vmcnt retires in order)
-                load_wq(wq[(t + 2) % 3], cc * 9 + t + 2);
-                if (wave_live) {
-                    const char* As = Abuf + ab * A_BYTES + ((t / 3) * PW + (t % 3)) * RSTR;
-#pragma unroll
-                    for (int kk = 0; kk < CK / 16; ++kk) {
-                        uint4 xf[2];
-#pragma unroll
-                        for (int bb = 0; bb < 2; ++bb) xf[bb] = *reinterpret_cast<const uint4*>(As + a_frag[bb] + kk * 32);
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int bb = 0; bb < 2; ++bb) acc[a][bb] = E::mfma(wq[t % 3][a][kk], xf[bb], acc[a][bb]);
-                    }
-                }
-                if (t == 8) {
-                    if (c + 1 < c_end) store_patch(ab ^ 1, c + 1);
-                    __syncthreads();
-                }
-            }
-        }
-    } else {
     if (total > 0) {
         load_patch(c_begin);
         load_w(w_r0, 0);
@@ -275,7 +218,6 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
         step(it, std::integral_constant<int, 0>{}, w_r0, w_r1);
         if (it + 1 < total) step(it + 1, std::integral_constant<int, 1>{}, w_r1, w_r0);
     }
-    }      // !WREG
 
     // ---- epilogue (same scheme as conv_gemm.hip): one 64-pixel wave-row group at a time through LDS ----
     float* Cs = reinterpret_cast<float*>(smem);
@@ -352,19 +294,17 @@ bool imd_conv_patch_supported(const ConvGemmParams& p) {
 
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
     if (!imd_conv_patch_supported(p)) return imd_set_error("conv_patch: unsupported geometry (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 32 == 0)");
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
-    const bool wreg = !(g_gemm_flags & 512);          // knob 2 bit 9: the round-1/2 form (weights staged through LDS, one barrier per tap)
-    typedef void (*kern_t)(const ConvGemmParams);
-    const kern_t kern = wreg ? (h ? conv3x3_patch_kernel<true, true> : conv3x3_patch_kernel<false, true>)
-                             : (h ? conv3x3_patch_kernel<true, false> : conv3x3_patch_kernel<false, false>);
-    if (!attr_set[h][wreg]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_LDS);
+    const void* kern = h ? reinterpret_cast<const void*>(conv3x3_patch_kernel<true>) : reinterpret_cast<const void*>(conv3x3_patch_kernel<false>);
+    if (!attr_set[h]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_LDS);
         if (e != hipSuccess) return imd_set_error("conv_patch: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h][wreg] = true;
+        attr_set[h] = true;
     }
     const int B = p.M / (p.Hout * p.Wout);
     const long blocks = (long)B * ((p.Hin + TH - 1) / TH) * ((p.Win + TW - 1) / TW) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
+    if (h) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
+    else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
     return imd_check_launch("conv_patch");
 }

@@ -246,7 +246,7 @@ def full_pipe(request):
     import bench
     dev = torch.device("cuda", 0)
     pipe = bench.build_pipeline(dev, request.param, 0)
-    inp = bench.synthetic_inputs(argparse.Namespace(batch=4, res=512), dev, request.param, 0, 1)
+    inp = bench.synthetic_inputs(512, 512, 4, dev, request.param, 0, 1)
     yield pipe, inp, request.param
     del pipe
     torch.cuda.empty_cache()

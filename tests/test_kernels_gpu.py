@@ -501,7 +501,7 @@ def test_attention(ops, D, B, N, L1, L2, dt):
     assert_close(out, ref, atol=1e-2, rtol=1e-2, what=f"attention D={D}")
 
 
-@pytest.mark.parametrize("variant", [10, 11, 9, 7, 12, 13, 14, 15, 16])
+@pytest.mark.parametrize("variant", [10, 11, 9, 7])
 @pytest.mark.parametrize("pad_one", [True, False])
 @pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (530, 700, 0), (512, 1000, 520)])
 @DTS

@@ -6,12 +6,13 @@ import torch
 from imagdressing_amd import ops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--variant", type=int, default=10)
+ap.add_argument("--variant", type=int, default=0, help="knob 0 value (0 = library default)")
+ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--zero", action="store_true")
 ap.add_argument("--seconds", type=float, default=4.0)
 ap.add_argument("--what", default="attn", choices=["attn", "idle"])
 a = ap.parse_args()
-dt = torch.bfloat16
+dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 D, N, H, Bimg = 40, 4096, 8, 4
 B = 2 * Bimg
 dpk, dpv = ops.attn_padded_dims(D)
@@ -24,7 +25,8 @@ kr = ops.k_buffer((1, H, N, dpk), D, dt, "cuda"); kr[..., :D] = r(1, H, N, D)
 vr = torch.zeros(1, H, dpv, N, dtype=dt, device="cuda"); vr[:, :, :D, :N] = r(1, H, D, N)
 s2 = torch.cat([torch.ones(Bimg), torch.zeros(Bimg)]).cuda()
 out = torch.empty(B, N, H * D, dtype=dt, device="cuda")
-ops.L.check(ops.L.load().imd_set_tuning(0, a.variant))
+if a.variant:
+    ops.L.check(ops.L.load().imd_set_tuning(0, a.variant))
 def go():
     ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=N, k2=kr, v2t=vr, scale2=s2, L2=N, L2P=N, kv2_bdiv=B, k_pad_one=True)
 samples, stop = [], False
@@ -52,4 +54,15 @@ while time.time() - t0 < a.seconds:
 e1.record(); torch.cuda.synchronize()
 stop = True; th.join()
 us = e0.elapsed_time(e1) * 1e3 / max(n, 1)
-print(json.dumps(dict(variant=a.variant, zero=a.zero, what=a.what, launches=n, us_per_launch=round(us, 1), samples=samples[len(samples)//3:][:12])))
+def num(x):
+    try:
+        return float(str(x).strip("()MhzW "))
+    except ValueError:
+        return None
+tail = samples[len(samples) // 3:]
+pw = [num(r.get("Current Socket Graphics Package Power (W)")) for r in tail]
+ck = [num(r.get("sclk clock speed:")) for r in tail]
+pw, ck = [v for v in pw if v], [v for v in ck if v]
+print(json.dumps(dict(variant=a.variant, dtype=a.dtype, zero=a.zero, what=a.what, launches=n, us_per_launch=round(us, 1),
+                      power_w=round(sum(pw) / len(pw), 1) if pw else None, sclk_mhz=round(sum(ck) / len(ck), 1) if ck else None,
+                      n_samples=len(tail), samples=tail[:6])))
