@@ -33,6 +33,7 @@ class ConvGemmParams(C.Structure):
         ("x_bytes", C.c_uint32), ("w_bytes", C.c_uint32), ("flags", C.c_int),
         ("gn_a", C.c_void_p), ("gn_b", C.c_void_p), ("gn_silu", C.c_int), ("pad_br_only", C.c_int),
         ("splitk_counters", C.c_void_p),
+        ("gn_stats_out", C.c_void_p), ("gn_stats_groups", C.c_int),
     ]
 
 
@@ -57,7 +58,7 @@ class GroupNormParams(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partial", C.c_void_p),
         ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("G", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int),
-        ("eps", C.c_float), ("silu", C.c_int), ("dtype", C.c_int),
+        ("eps", C.c_float), ("silu", C.c_int), ("dtype", C.c_int), ("nparts", C.c_int),
     ]
 
 
@@ -96,6 +97,7 @@ SYMBOLS = {
     "imd_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p]),
     "imd_groupnorm_coeffs": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "imd_conv_patch_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
+    "imd_conv_patch_stats_parts": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_gemm_dma_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_row_linear": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int, C.c_float, C.c_void_p]),
     "imd_row_linear_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),

@@ -235,6 +235,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
             use_col_pre = true;
         }
     }
+    // GroupNorm statistics of the output tile (gn_stats_out): a thread keeps the same 8 channels for every row it emits, so it
+    // accumulates (sum, sum of squares) of its final values for the at most two groups those channels belong to
+    const bool want_stats = p.gn_stats_out != nullptr && slab == nullptr;
+    const int cpg = want_stats ? p.N / p.gn_stats_groups : 1;
+    const int st_n = n0 + (tid % CPR) * 8;
+    const int st_split = min(8, (st_n / cpg + 1) * cpg - st_n);       // channels [0, split) of the chunk -> its first group
+    float st[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int wr = 0; wr < 2; ++wr) {
         if ((wave >> 1) == wr) {
@@ -262,10 +269,44 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
                 slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, p.splitk_counters != nullptr);
             } else {
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HW, use_col_pre, col_pre0, col_pre1);
+                const int nv = (n + 8 <= p.N) ? 8 : 4;
+                epilogue8<F16>(p, v, m, n, nv, HW, use_col_pre, col_pre0, col_pre1);
+                if (want_stats) {               // v now holds the final values (bias / vector / residual / activation applied)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (e < nv) {
+                            if (e < st_split) { st[0] += v[e]; st[1] += v[e] * v[e]; }
+                            else { st[2] += v[e]; st[3] += v[e] * v[e]; }
+                        }
+                    }
+                }
             }
         }
         if (wr == 0) __syncthreads();
+    }
+    if (want_stats) {
+        __syncthreads();                        // the fp32 tile in LDS is dead: reuse its head for the 256 x 4 partials
+        float* red = reinterpret_cast<float*>(smem);
+        *reinterpret_cast<float4*>(red + tid * 4) = make_float4(st[0], st[1], st[2], st[3]);
+        __syncthreads();
+        const int G = p.gn_stats_groups;
+        if (tid < G) {                          // fixed summation order: column chunk, then row lane (deterministic)
+            const int g = tid;
+            float S = 0.f, Q = 0.f;
+            for (int j = 0; j < CPR; ++j) {
+                const int nj = n0 + 8 * j;
+                if (nj >= p.N) break;
+                const int gj = nj / cpg;
+                if (gj == g || gj + 1 == g) {
+                    const int o = (gj == g) ? 0 : 2;
+                    for (int rl = 0; rl < 256 / CPR; ++rl) { S += red[(j + CPR * rl) * 4 + o]; Q += red[(j + CPR * rl) * 4 + o + 1]; }
+                }
+            }
+            const int nparts = tiles_y * tiles_x * n_tiles;
+            const int part = (ty * tiles_x + tx) * n_tiles + tile_n;
+            float* dst = p.gn_stats_out + (((size_t)b * nparts + part) * G + g) * 2;
+            dst[0] = S; dst[1] = Q;
+        }
     }
     // K slices summed in-kernel by the tile's last-arriving workgroup (gemm_common.h::splitk_last_arrival)
     if (slab != nullptr && p.splitk_counters != nullptr) {
@@ -286,6 +327,14 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 }
 
 }  // namespace
+
+// statistic partials per image written through gn_stats_out (0: this launch cannot produce them)
+int imd_conv_patch_stats_parts_of(const ConvGemmParams& p) {
+    if (!imd_conv_patch_supported(p) || p.split_k > 1 || p.out_f32 || p.gn_stats_groups <= 0 || p.gn_stats_groups > 64 ||
+        p.N % p.gn_stats_groups || (p.N / p.gn_stats_groups) < 8)
+        return 0;
+    return ((p.Hin + TH - 1) / TH) * ((p.Win + TW - 1) / TW) * ((p.N + BN - 1) / BN);
+}
 
 bool imd_conv_patch_supported(const ConvGemmParams& p) {
     return p.taps == 9 && p.stride == 1 && !p.ups && !p.pad_br_only && p.Hin == p.Hout && p.Win == p.Wout && p.Hin >= TH &&

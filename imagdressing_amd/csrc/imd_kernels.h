@@ -25,6 +25,7 @@ int imd_conv_gemm_choose_cfg(int M, int N);
 int imd_conv_gemm_choose_split(int M, int N, int K, int cfg);
 int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
 bool imd_conv_patch_supported(const ConvGemmParams& p);
+int imd_conv_patch_stats_parts_of(const ConvGemmParams& p);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
 bool imd_row_linear_supported(const ConvGemmParams& p);                                    // row_linear.hip
 int imd_launch_row_linear(const ConvGemmParams& p, int ln, float ln_eps, hipStream_t s);

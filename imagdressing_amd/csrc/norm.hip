@@ -115,7 +115,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormPar
     const int tid = threadIdx.x;
     const int cpg = p.C / p.G;
     const int chunk = blockIdx.x, b = blockIdx.y;
-    const int nchunks = gn_chunks(p.B, p.HW, p.C);
+    const int nchunks = p.nparts > 0 ? p.nparts : gn_chunks(p.B, p.HW, p.C);       // (nparts: partials written by the producer of x)
     {   // fold this batch entry's per-chunk partials: ALL threads take part (group = tid % G, every parts-th
         // chunk each) so the ~100 partial loads of a block are independent and in flight together
         const int parts = GN_THREADS / p.G;
@@ -415,6 +415,12 @@ int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s) {
     const int chunks = gn_chunks(p.B, p.HW, p.C);
     dim3 grid(chunks, p.B);
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if (p.nparts > 0) {              // statistics came with the tensor (convolution epilogue): normalise only
+        if (p.nparts > 4096) return imd_set_error("groupnorm: nparts %d is implausible", p.nparts);
+        if (h) hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(GN_THREADS), 0, s, p);
+        else hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(GN_THREADS), 0, s, p);
+        return imd_check_launch("groupnorm apply (producer statistics)");
+    }
     if (chunks > GN_TWO_LEVEL_CHUNKS) {
         float* ca = p.partial + (size_t)p.B * chunks * p.G * 2;
         float* cb = ca + (size_t)p.B * p.C;

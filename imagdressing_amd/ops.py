@@ -134,6 +134,8 @@ SPLITK_IN_KERNEL = False   # opt-in: K slices summed by each tile's last-arrivin
                            # measured SLOWER end to end, 660.5 -> 687.5 ms: the slab traffic must bypass the per-XCD L2s)
 FUSED_FF = True            # engines run norm3 -> GEGLU feed-forward -> + residual of the 320-channel blocks as one launch (ff_fused.hip)
 FUSED_FF_MIN_ROWS = 24576  # below this the 128-row workgroups cannot fill the chip (one per CU at 32768 rows) and the tiled kernels win
+import os as _os
+FUSED_GN_STATS = _os.environ.get("IMD_FUSED_GN_STATS", "1") != "0"   # 3x3 convs on the halo-patch kernel emit the GroupNorm statistics of their output from the epilogue (A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 _GEMM_TABLE = None
@@ -161,7 +163,7 @@ def conv_gemm(
     rowvec_off: int = 0, res: Optional[torch.Tensor] = None, res_ld: Optional[int] = None, out_scale: float = 1.0,
     act: int = ACT_NONE, out_f32: bool = False,
     heads: Optional[dict] = None, cfg: int = -1, split_k: int = 0,
-    gn: Optional[tuple] = None, pad_br_only: bool = False, ln_eps: Optional[float] = None,
+    gn: Optional[tuple] = None, pad_br_only: bool = False, ln_eps: Optional[float] = None, gn_stats_groups: int = 0,
 ) -> Optional[torch.Tensor]:
     """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
 
@@ -171,6 +173,9 @@ def conv_gemm(
     of the input into the 3x3 halo-patch kernel (tile config 5).
     ``ln_eps``: LayerNorm WITHOUT affine over the K channels of every row of ``x`` is applied on the fly (row-resident kernel,
     K = 320 and N <= 320 only; fold gamma / beta into ``w`` / ``bias`` with :func:`fold_layernorm_affine`).
+    ``gn_stats_groups`` = G: when the launch lands on the halo-patch kernel without K slices, its epilogue also writes the GroupNorm(G)
+    statistics of the OUTPUT (per-tile fp32 partials); they ride on the returned tensor (``_imd_gn_stats``) and the next
+    :func:`group_norm` of that tensor skips its statistics pass.  Silently not produced on every other path (FUSED_GN_STATS = False: never).
     """
     ensure_device(x.device)
     K = taps * Cin
@@ -253,7 +258,19 @@ def conv_gemm(
         p.splitk_ws = splitk_workspace(split_k * M * N, x.device).data_ptr()
         if SPLITK_IN_KERNEL:
             p.splitk_counters = splitk_counters(x.device).data_ptr()
+    stats = None
+    if gn_stats_groups and FUSED_GN_STATS and cfg == 5 and split_k == 1 and heads is None and not out_f32 and act != ACT_GEGLU:
+        p.gn_stats_groups = gn_stats_groups
+        nparts = lib.imd_conv_patch_stats_parts(C.byref(p))
+        if nparts > 0:
+            Bimg = M // (Hout * Wout)
+            stats = (torch.empty((Bimg, nparts, gn_stats_groups, 2), dtype=torch.float32, device=x.device), nparts, gn_stats_groups)
+            p.gn_stats_out = stats[0].data_ptr()
+        else:
+            p.gn_stats_groups = 0
     L.check(lib.imd_conv_gemm(C.byref(p), cfg, _stream()))
+    if stats is not None:
+        out._imd_gn_stats = stats
     return out
 
 
@@ -349,7 +366,7 @@ def ff_geglu_fused(x2d: torch.Tensor, packed: dict, ln_eps: float = 1e-5, out: O
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
                 rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0, gn=None,
-                pad_br_only=False) -> torch.Tensor:
+                pad_br_only=False, gn_stats_groups=0) -> torch.Tensor:
     """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout].  ``pad_br_only``: F.pad(x, (0, 1, 0, 1)) + conv(padding=0) (VAE encoder)."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -358,8 +375,12 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1
     M = B * Ho * Wo
     out = conv_gemm(x, w, M=M, N=Cout, Cin=Cin, taps=taps, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups,
                     bias=bias, rowvec=rowvec, rowvec_stride=rowvec_stride, rowvec_off=rowvec_off, res=res, out_scale=out_scale, act=act,
-                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn, pad_br_only=pad_br_only)
-    return out.view(B, Ho, Wo, -1)
+                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn, pad_br_only=pad_br_only, gn_stats_groups=gn_stats_groups)
+    r = out.view(B, Ho, Wo, -1)
+    st = getattr(out, "_imd_gn_stats", None)
+    if st is not None:
+        r._imd_gn_stats = st          # (a view is a new tensor object: carry the producer's GroupNorm statistics over)
+    return r
 
 
 # bench.py installs {"match": fn(**shape) -> bool, "events": []} to bracket matching launches with HIP
@@ -466,6 +487,9 @@ def group_norm(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5, silu=False,
     p.partial = part.data_ptr()
     p.B, p.HW, p.C, p.G, p.x_ld, p.y_ld = B, HW, Cc, groups, Cc, Cc
     p.eps, p.silu = eps, int(silu)
+    st = getattr(x, "_imd_gn_stats", None)        # statistics written by the epilogue of the convolution that produced x
+    if st is not None and st[2] == groups and st[0].shape[0] == B and FUSED_GN_STATS:
+        p.partial, p.nparts = st[0].data_ptr(), st[1]
     L.check(lib.imd_groupnorm(C.byref(p), _stream()))
     return out
 

@@ -332,10 +332,12 @@ class ResnetBlock:
 
     def __call__(self, x, temb_all):
         h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, groups=self.groups, eps=1e-5, silu=True)
-        h = self.conv1(h, rowvec=temb_all, rowvec_stride=temb_all.shape[1], rowvec_off=self.temb_off)
+        # (gn_stats_groups: where the conv runs on the halo-patch kernel its epilogue also emits the GroupNorm statistics of its
+        # output, and the next group_norm of that tensor -- norm2 here, the following block's norm after conv2 -- skips its own pass)
+        h = self.conv1(h, rowvec=temb_all, rowvec_stride=temb_all.shape[1], rowvec_off=self.temb_off, gn_stats_groups=self.groups)
         h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, groups=self.groups, eps=1e-5, silu=True)
         sc = x if self.shortcut is None else self.shortcut(x)
-        return self.conv2(h, res=sc)
+        return self.conv2(h, res=sc, gn_stats_groups=self.groups)
 
 
 class _Encoder(PretrainedMixin):

@@ -74,6 +74,13 @@ typedef struct imd_conv_gemm_params {
     int* splitk_counters; /* split_k > 1 only.  NULL: the K slices are summed by a second launch (fixed order).  Otherwise >=
                           * IMD_SPLITK_COUNTERS ints that are ZERO on entry and are left zero: every output tile's last-arriving
                           * workgroup sums the slices itself, in the same fixed order (bit-identical results, one launch less) */
+    /* GroupNorm statistics of the OUTPUT produced in the epilogue (cfg 5, split_k == 1, row-major 16-bit output, N %
+     * gn_stats_groups == 0): every workgroup writes the fp32 (sum, sum of squares) of its tile's final values per group to
+     * gn_stats_out[((b * nparts + part) * G + g) * 2], part = (pixel tile of the image) * n_tiles + channel tile, nparts =
+     * imd_conv_patch_stats_parts(); groups outside the tile get zeros.  The next imd_groupnorm on that tensor passes the buffer
+     * as `partial` with `nparts` and skips its statistics pass (ResnetBlock2D: conv1 -> norm2, conv2 -> the next block's norm). */
+    float* gn_stats_out;
+    int gn_stats_groups;
 } imd_conv_gemm_params;
 #define IMD_SPLITK_COUNTERS 16384
 
@@ -127,6 +134,9 @@ typedef struct imd_groupnorm_params {
     float eps;
     int silu;
     int dtype;
+    int nparts;          /* 0: imd_groupnorm computes the statistics itself (two launches).  > 0: `partial` already holds
+                          * [B][nparts][G][2] fp32 (sum, sum of squares) partials of x written by the PRODUCER of x -- the
+                          * convolution epilogue, imd_conv_gemm_params.gn_stats_out -- and only the normalise pass is launched */
 } imd_groupnorm_params;
 
 typedef struct imd_layernorm_params {
@@ -211,6 +221,8 @@ int imd_groupnorm_workspace_floats(int B, int HW, int C, int G);
 int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* coef_b, void* stream);
 /* 1 iff tile config 5 (LDS-resident halo patch: 3x3, stride 1, H % 8 == 0, W % 16 == 0, Cin % 32 == 0) can run *p. */
 int imd_conv_patch_supported(const imd_conv_gemm_params* p);
+/* number of statistic partials per image the halo-patch kernel writes for this geometry (gn_stats_out), 0 if it cannot */
+int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p);
 /* 1 iff tile config 16 (256 x 256 x 64 LDS-DMA tile kernel, gemm_dma.hip: plain linear layer, K % 64 == 0, no K split) can run *p. */
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p);
 

@@ -411,6 +411,40 @@ def test_conv3x3_fused_groupnorm(ops, B, H, W, Cin, Cout, silu, dt):
     assert_close(out, two.float(), atol=2 * TOL[dt], what="fused vs unfused")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,G", [(2, 32, 32, 320, 320, 32), (1, 16, 32, 64, 640, 32), (1, 24, 40, 64, 320, 32), (2, 16, 16, 96, 128, 8),
+                                               (1, 64, 64, 32, 1280, 32)])
+@DTS
+def test_conv3x3_epilogue_groupnorm_statistics(ops, B, H, W, Cin, Cout, G, dt):
+    """The halo-patch conv's epilogue emits the GroupNorm statistics of its OUTPUT (bias, time-embedding vector and residual
+    applied; groups that straddle 128-channel tiles, ragged pixel tiles): folded, they equal the statistics of the output tensor,
+    and the next group_norm of that tensor -- which then skips its own statistics pass -- equals F.group_norm."""
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, H, W, Cout).to(dt)
+    gamma = 1.0 + 0.2 * rnd(6, Cout); beta = 0.2 * rnd(7, Cout)
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), cfg=5, split_k=1,
+                          gn_stats_groups=G)
+    st = getattr(out, "_imd_gn_stats", None)
+    assert st is not None and st[2] == G, "the halo-patch kernel must hand its statistics on"
+    part, nparts, _ = st
+    folded = part.float().sum(1).cpu()                                   # [B, G, 2]
+    o = out.float().cpu().permute(0, 3, 1, 2).reshape(B, G, -1)          # [B, G, cpg * H * W] (values after 16-bit rounding)
+    n = o.shape[-1]
+    assert torch.allclose(folded[..., 0] / n, o.mean(-1), atol=2e-3), "group means"
+    assert torch.allclose(folded[..., 1] / n, (o * o).mean(-1), rtol=5e-3, atol=2e-3), "group second moments"
+    fused = ops.group_norm(out, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=True)
+    plain_in = out.clone()                                               # (a clone carries no statistics: two-launch path)
+    assert getattr(plain_in, "_imd_gn_stats", None) is None
+    plain = ops.group_norm(plain_in, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=True)
+    ref = F.silu(F.group_norm(out.float().cpu().permute(0, 3, 1, 2), G, gamma, beta, eps=1e-5)).permute(0, 2, 3, 1)
+    assert_close(fused, ref, atol=2 * TOL[dt], what="group_norm on producer statistics")
+    assert_close(fused, plain.float(), atol=2 * TOL[dt], what="producer statistics vs own pass")
+    # K slices finish in another launch: no statistics, silently
+    out2 = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=5, split_k=2 if Cin >= 64 else 1, gn_stats_groups=G)
+    assert (getattr(out2, "_imd_gn_stats", None) is None) == (Cin >= 64)
+
+
 @DTS
 def test_conv_epilogue_rowvec_residual_scale(ops, dt):
     B, H, W, Cin, Cout = 2, 8, 8, 64, 128
