@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "gemm_common.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -43,7 +44,21 @@ __device__ constexpr unsigned char kColPix[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 
                                                   30, 31, 16, 17, 22, 23, 24, 25, 26, 27, 28, 29, 18, 19, 20, 21};
 constexpr int W_VECS = BN * (CK / 8) / 256;             // 2
 
-template <bool F16>
+// DMA (round 3): BOTH operands reach LDS by LDS-DMA (`buffer_load ... lds`), nothing is staged through registers.  The halo patch
+// of a 32-channel chunk (180 pixel rows x 64 B, 12 one-KB pieces) and the weight tile of a tap (128 rows x 64 B, 8 pieces) are
+// written lane-linear, i.e. as unpadded 64-byte rows; fragment reads stay conflict-free through a SOURCE-side swizzle -- piece
+// c of row r sits at position c ^ ((r >> 2) & 3), so the 16 rows of a ds_read_b128 lane group (any 8 + 8 consecutive rows of the
+// patch, or 4 aligned row quadruples of the weight tile) fall on 16 distinct 16-byte bank slots.  Weight tiles run through a
+// ring of three taps (tap t + 2 in flight while tap t is multiplied, counted s_waitcnt); the next chunk's patch is fetched at
+// tap 5 into the other patch buffer; out-of-image halo pixels and rows / taps past the end are out-of-range offsets that the
+// DMA turns into zeros.  Against the register-staged form: no VGPR -> LDS stores (the slow LDS write path: ~79 B/clk) and no
+// staging registers.  48 KB of LDS -> 3 workgroups per CU as before.  The fused GroupNorm prologue needs the values in
+// registers and keeps the register-staged kernel.
+constexpr int AB_D = 12 * 1024, WB_D = 8 * 1024, NWR_D = 3;
+constexpr int PATCH_DMA_LDS = 2 * AB_D + NWR_D * WB_D;            // 49,152 (>= EPI_LDS)
+static_assert(PATCH_DMA_LDS >= EPI_LDS, "the epilogue tile must fit the main-loop LDS");
+
+template <bool F16, bool DMA>
 __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmParams p) {
     using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,6 +190,94 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     // the last channel tile of N = 320 / 960 ... is half empty: waves that own no valid channel skip the matrix work
     const bool wave_live = n0 + wn0 < p.N;
 
+    if constexpr (DMA) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+        const v4i_t dx = raw_rsrc(p.x, p.x_bytes), dw = raw_rsrc(p.w, p.w_bytes);
+        uint32_t a_src[3], w_src[2];          // byte offsets of this lane's 16-byte pieces at chunk 0 / tap 0 (OOB: zeros)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int slot = (wv * 3 + i) * 64 + lane, pp = slot >> 2, piece = (slot & 3) ^ ((pp >> 2) & 3);
+            a_src[i] = OOB;
+            if (pp < NPIX) {
+                const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    a_src[i] = (uint32_t)(((b * H + iy) * W + ix) * p.x_pix_stride + piece * 8) * 2u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int slot = (wv * 2 + i) * 64 + lane, row = slot >> 2, piece = (slot & 3) ^ ((row >> 2) & 3);
+            w_src[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8) * 2) : OOB;
+        }
+        auto dma_patch = [&](int c, int buf) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                dma16(dx, smem_base + buf * AB_D + (wv * 3 + i) * 1024, (a_src[i] != OOB && c < c_end) ? a_src[i] + (uint32_t)(c * CK * 2) : OOB);
+        };
+        auto dma_w = [&](int it, int ring) {
+            const int cq = it / 9;
+            const uint32_t koff = (uint32_t)(((it - cq * 9) * p.Cin + (c_begin + cq) * CK) * 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                dma16(dw, smem_base + 2 * AB_D + ring * WB_D + (wv * 2 + i) * 1024, (w_src[i] != OOB && it < total) ? w_src[i] + koff : OOB);
+        };
+        int w_fr[2], a_row[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int row = wn0 + a * 32 + col;
+            w_fr[a] = row * 64 + ((hi ^ ((row >> 2) & 3)) << 4);         // 16-deep slice kk = 0; kk = 1 is the same address ^ 32
+        }
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            const int q = wm0 + bb * 32 + cpix;
+            a_row[bb] = (q / TW) * PW + (q % TW);
+        }
+        if (total > 0) {
+            dma_patch(c_begin, 0);
+            dma_w(0, 0);
+            dma_w(1, 1);
+        }
+        dma_wait();
+        __syncthreads();
+#pragma unroll 1
+        for (int cc = 0; cc < c_end - c_begin; ++cc) {
+            const int ab = cc & 1;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {                  // 9 taps = 3 turns of the weight ring: ring slots are compile-time
+                dma_w(cc * 9 + t + 2, (t + 2) % 3);
+                if (t == 5) dma_patch(c_begin + cc + 1, ab ^ 1);       // (always 3 pieces, zeros past the last chunk: the counted waits rely on it)
+                if (wave_live) {
+                    const char* As = smem + ab * AB_D;
+                    const char* Ws = smem + 2 * AB_D + (t % 3) * WB_D;
+                    int xa[2];
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int rw = a_row[bb] + (t / 3) * PW + (t % 3);
+                        xa[bb] = rw * 64 + ((hi ^ ((rw >> 2) & 3)) << 4);
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < CK / 16; ++kk) {
+                        uint4 wf[2], xf[2];
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + (w_fr[a] ^ (kk * 32)));
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) xf[bb] = *reinterpret_cast<const uint4*>(As + (xa[bb] ^ (kk * 32)));
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int bb = 0; bb < 2; ++bb) acc[a][bb] = E::mfma(wf[a], xf[bb], acc[a][bb]);
+                    }
+                }
+                // the next tap's weight pieces have landed: everything but this tap's two pieces (and, at taps 5 and 6, the three
+                // patch pieces issued behind them at tap 5) may stay in flight
+                if (t == 5 || t == 6) dma_wait_keep5(); else dma_wait_keep2();
+                __syncthreads();
+            }
+        }
+        dma_wait();                  // zero-fill pieces past the end are still landing: the epilogue reuses this LDS
+        __syncthreads();
+    } else {
     if (total > 0) {
         load_patch(c_begin);
         load_w(w_r0, 0);
@@ -218,6 +321,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
         step(it, std::integral_constant<int, 0>{}, w_r0, w_r1);
         if (it + 1 < total) step(it + 1, std::integral_constant<int, 1>{}, w_r1, w_r0);
     }
+    }      // !DMA
 
     // ---- epilogue (same scheme as conv_gemm.hip): one 64-pixel wave-row group at a time through LDS ----
     float* Cs = reinterpret_cast<float*>(smem);
@@ -343,17 +447,22 @@ bool imd_conv_patch_supported(const ConvGemmParams& p) {
 
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
     if (!imd_conv_patch_supported(p)) return imd_set_error("conv_patch: unsupported geometry (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 32 == 0)");
-    static bool attr_set[2] = {false, false};
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
     const bool h = p.dtype == IMD_DTYPE_F16;
-    const void* kern = h ? reinterpret_cast<const void*>(conv3x3_patch_kernel<true>) : reinterpret_cast<const void*>(conv3x3_patch_kernel<false>);
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, PATCH_LDS);
+    // LDS-DMA staging of both operands unless the fused GroupNorm prologue (values needed in registers) is asked for, or tuning knob 2
+    // bit 9 selects the round-1/2 register-staged form (A/B)
+    const bool dma = p.gn_a == nullptr && !(g_gemm_flags & 512);
+    typedef void (*kern_t)(const ConvGemmParams);
+    const kern_t kern = dma ? (h ? conv3x3_patch_kernel<true, true> : conv3x3_patch_kernel<false, true>)
+                            : (h ? conv3x3_patch_kernel<true, false> : conv3x3_patch_kernel<false, false>);
+    const int lds = dma ? PATCH_DMA_LDS : PATCH_LDS;
+    if (!attr_set[h][dma]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return imd_set_error("conv_patch: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h] = true;
+        attr_set[h][dma] = true;
     }
     const int B = p.M / (p.Hout * p.Wout);
     const long blocks = (long)B * ((p.Hin + TH - 1) / TH) * ((p.Win + TW - 1) / TW) * ((p.N + BN - 1) / BN);
-    if (h) hipLaunchKernelGGL(conv3x3_patch_kernel<true>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
-    else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH_LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), lds, s, p);
     return imd_check_launch("conv_patch");
 }

@@ -366,9 +366,20 @@ def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups, dt):
     (1, 8, 16, 1280, 128, 8),
     # ragged maps: tiles hang over the right / bottom edge (the 96 x 72 latent of BASELINE configs[4] and its 48 x 36 level)
     (1, 96, 72, 320, 320, 1), (2, 48, 36, 640, 640, 2), (1, 12, 18, 64, 64, 1), (2, 9, 17, 32, 40, 1)])
+@pytest.mark.parametrize("reg_staged", [False, True], ids=["dma", "regs"])
 @DTS
-def test_conv3x3_halo_patch(ops, B, H, W, Cin, Cout, split, dt):
-    """tile config 5 (LDS-resident halo patch) == F.conv2d, with the full epilogue and with K slices"""
+def test_conv3x3_halo_patch(ops, B, H, W, Cin, Cout, split, dt, reg_staged):
+    """tile config 5 (LDS-resident halo patch) == F.conv2d, with the full epilogue and with K slices; both staging paths: every
+    operand by LDS-DMA with source-side swizzles (round 3, default) and through registers (tuning knob 2, bit 9)"""
+    lib = ops.L.load()
+    ops.L.check(lib.imd_set_tuning(2, 23 | (512 if reg_staged else 0)))
+    try:
+        _halo_patch_case(ops, B, H, W, Cin, Cout, split, dt)
+    finally:
+        ops.L.check(lib.imd_set_tuning(2, 23))
+
+
+def _halo_patch_case(ops, B, H, W, Cin, Cout, split, dt):
     x = rnd(1, B, Cin, H, W).to(dt)
     w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
     b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, H, W, Cout).to(dt)
