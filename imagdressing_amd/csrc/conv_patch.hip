@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     const int hi = lane >> 5, col = lane & 31;
     const int cpix = kColPix[col];             // pixel (0..31) this lane's MFMA column stands for
 
-    const int H = p.Hin, W = p.Win;
+    const int H = p.Hout, W = p.Wout;          // output map = logical input map (fused nearest-2x upsample: twice the stored input, DMA path only)
     // ragged maps (96 x 72 latents of the 768 x 576 configuration: W = 72, 36, 18): the last tile row / column hangs over the
     // edge; its patch pixels outside the image read as zero like any halo pixel and its output pixels are not stored
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
@@ -200,9 +200,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
             const int slot = (wv * 3 + i) * 64 + lane, pp = slot >> 2, piece = (slot & 3) ^ ((pp >> 2) & 3);
             a_src[i] = OOB;
             if (pp < NPIX) {
-                const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;
-                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-                    a_src[i] = (uint32_t)(((b * H + iy) * W + ix) * p.x_pix_stride + piece * 8) * 2u;
+                const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;        // logical pixel; the zero halo is applied AFTER the upsample
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;     // nearest-2x: source pixel = logical pixel >> 1
+                    a_src[i] = (uint32_t)(((b * p.Hin + sy) * p.Win + sx) * p.x_pix_stride + piece * 8) * 2u;
+                }
             }
         }
 #pragma unroll
@@ -437,12 +439,15 @@ int imd_conv_patch_stats_parts_of(const ConvGemmParams& p) {
     if (!imd_conv_patch_supported(p) || p.split_k > 1 || p.out_f32 || p.gn_stats_groups <= 0 || p.gn_stats_groups > 64 ||
         p.N % p.gn_stats_groups || (p.N / p.gn_stats_groups) < 8)
         return 0;
-    return ((p.Hin + TH - 1) / TH) * ((p.Win + TW - 1) / TW) * ((p.N + BN - 1) / BN);
+    return ((p.Hout + TH - 1) / TH) * ((p.Wout + TW - 1) / TW) * ((p.N + BN - 1) / BN);
 }
 
 bool imd_conv_patch_supported(const ConvGemmParams& p) {
-    return p.taps == 9 && p.stride == 1 && !p.ups && !p.pad_br_only && p.Hin == p.Hout && p.Win == p.Wout && p.Hin >= TH &&
-           p.Win >= TW && (p.Cin % CK) == 0 && p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU;
+    // the fused nearest-2x upsample (Upsample2D: interpolate -> conv) is a source-pixel map of the LDS-DMA staging only
+    const bool geom = p.ups ? (p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win && p.gn_a == nullptr && !(g_gemm_flags & 512))
+                            : (p.Hin == p.Hout && p.Win == p.Wout);
+    return p.taps == 9 && p.stride == 1 && !p.pad_br_only && geom && p.Hout >= TH && p.Wout >= TW && (p.Cin % CK) == 0 &&
+           p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU;
 }
 
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
@@ -462,7 +467,7 @@ int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
         attr_set[h][dma] = true;
     }
     const int B = p.M / (p.Hout * p.Wout);
-    const long blocks = (long)B * ((p.Hin + TH - 1) / TH) * ((p.Win + TW - 1) / TW) * ((p.N + BN - 1) / BN);
+    const long blocks = (long)B * ((p.Hout + TH - 1) / TH) * ((p.Wout + TW - 1) / TW) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), lds, s, p);
     return imd_check_launch("conv_patch");
 }

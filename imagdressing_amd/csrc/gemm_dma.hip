@@ -147,7 +147,163 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const ConvGemmParams p
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// 128 x 128 x 32 tiles, 4 waves, THREE-stage LDS-DMA ring (round 3; tile config 17).  The 256^2 kernel above keeps one
+// workgroup per CU and drains its DMA (vmcnt(0)) in front of every barrier with a single tile of lead; on the K = 640 ... 2560
+// linears of the UNet it only ties the register-staged tiles.  This shape is the halo-patch conv's recipe (conv_patch.hip)
+// applied to a plain [M, K] x [N, K]^T product: 16 KB stages (128 + 128 rows of 64 bytes), three of them = 48 KB -> three
+// workgroups per CU, tile t + 2 in flight while tile t is multiplied, counted `s_waitcnt vmcnt(4)` (each wave issues exactly
+// four 1-KB pieces per tile), unpadded 64-byte rows with piece c of row r at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128),
+// no staging registers, no VGPR -> LDS stores.  Epilogue = conv_gemm.hip's.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int G1_BM = 128, G1_BN = 128, G1_BK = 32, G1_NST = 3;
+constexpr int G1_STAGE = (G1_BM + G1_BN) * G1_BK * 2;      // 16384
+constexpr int G1_CLD = G1_BN + 4, G1_EROWS = 64;
+constexpr int G1_LDS = G1_NST * G1_STAGE;                  // 49152 >= 64 x 132 x 4
+static_assert(G1_LDS >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");
+
+template <bool F16>
+__global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParams p) {
+    using E = El<F16>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, col = lane & 31;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+
+    const int n_tiles = (p.N + G1_BN - 1) / G1_BN;
+    int tile_m, tile_n;
+    xcd_tile_order(p.flags, (p.M + G1_BM - 1) / G1_BM, n_tiles, tile_m, tile_n);
+    const int m0 = tile_m * G1_BM, n0 = tile_n * G1_BN;
+    const int nk = p.K / G1_BK;
+
+    // a stage = 16 pieces of 1 KB (16 rows x 64 B each): pieces 0..7 activation rows, 8..15 weight rows; wave w issues pieces
+    // w, w + 4 (activations) and 8 + w, 12 + w (weights)
+    const v4i_t ds_x = raw_rsrc(p.x, p.x_bytes), ds_w = raw_rsrc(p.w, p.w_bytes);
+    uint32_t soff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int id = (j & 1) * 4 + wave;                    // piece inside its operand tile
+        const int q = id * 64 + lane, row = q >> 2, pc = (q & 3) ^ ((row >> 2) & 3);
+        if (j >= 2) soff[j] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + pc * 8) * 2) : OOB;
+        else soff[j] = (m0 + row < p.M) ? (uint32_t)(((size_t)(m0 + row) * p.x_pix_stride + pc * 8) * 2) : OOB;
+    }
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    auto stage = [&](int kt, int slot) {                      // (tiles past the end: zero-fill pieces keep the counted waits uniform)
+        const uint32_t base = lds0 + (uint32_t)(slot * G1_STAGE);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int id = (j & 1) * 4 + wave + (j >= 2 ? 8 : 0);
+            dma16(j >= 2 ? ds_w : ds_x, base + (uint32_t)id * 1024u, (soff[j] == OOB || kt >= nk) ? OOB : soff[j] + (uint32_t)(kt * G1_BK * 2));
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment addresses (16-deep slice kk = 0; kk = 1 is the same address ^ 32): row offsets are multiples of 32, so the swizzle
+    // term (row >> 2) & 3 of row (base + col) is (col >> 2) & 3
+    const int fo = col * 64 + ((hi ^ ((col >> 2) & 3)) << 4);
+    const bool wave_live = n0 + wn0 < p.N && m0 + wm0 < p.M;
+
+    stage(0, 0);
+    stage(1, 1);
+    dma_wait_keep4();
+    __syncthreads();
+    int slot = 0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        stage(kt + 2, slot == 0 ? 2 : slot - 1);              // slot (kt + 2) % 3: last read at tile kt - 1, everybody is past that barrier
+        if (wave_live) {
+            const char* Xs = smem + slot * G1_STAGE + wm0 * 64;
+            const char* Ws = smem + slot * G1_STAGE + G1_BM * 64 + wn0 * 64;
+#pragma unroll
+            for (int kk = 0; kk < G1_BK / 16; ++kk) {
+                uint4 wf[2], xf[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + ((a * 32 * 64 + fo) ^ (kk * 32)));
+#pragma unroll
+                for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xs + ((b * 32 * 64 + fo) ^ (kk * 32)));
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[a][b] = E::mfma(wf[a], xf[b], acc[a][b]);
+            }
+        }
+        slot = slot == G1_NST - 1 ? 0 : slot + 1;
+        dma_wait_keep4();              // tile kt + 1 has landed (this wave's pieces; tile kt + 2's four stay in flight) ...
+        __syncthreads();               // ... and everybody's
+    }
+    dma_wait();                        // zero-fill pieces past the end: the epilogue reuses this LDS
+    __syncthreads();
+
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int HWo = p.Hout * p.Wout;
+    constexpr int CPR = G1_BN / 8;
+    constexpr int CHUNKS = G1_EROWS * CPR;
+    const bool colmajor = p.mode == OUT_HEADS;
+    float4 col_pre0 = make_float4(0, 0, 0, 0), col_pre1 = col_pre0;
+    bool use_col_pre = false;
+    if (!colmajor && (p.bias || p.rowvec)) {
+        const int bi_lo = m0 / HWo, bi_hi = (min(m0 + G1_BM, p.M) - 1) / HWo;
+        const int n = n0 + (tid % CPR) * 8;
+        if ((p.rowvec == nullptr || bi_lo == bi_hi) && n < p.N) {
+            load_col_addends(p, p.rowvec ? bi_lo : -1, n, (n + 8 <= p.N) ? 8 : 4, col_pre0, col_pre1);
+            use_col_pre = true;
+        }
+    }
+#pragma unroll 1
+    for (int wr = 0; wr < 2; ++wr) {
+        if ((wave >> 1) == wr) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float* dst = Cs + (b * 32 + col) * G1_CLD + wn0 + a * 32 + 8 * j + 4 * hi;
+                        *reinterpret_cast<float4*>(dst) = make_float4(acc[a][b][4 * j], acc[a][b][4 * j + 1], acc[a][b][4 * j + 2], acc[a][b][4 * j + 3]);
+                    }
+        }
+        __syncthreads();
+        for (int c = tid; c < CHUNKS; c += 256) {
+            int row, cc;
+            if (colmajor) { cc = (c / G1_EROWS) * 8; row = c - (c / G1_EROWS) * G1_EROWS; }
+            else { row = c / CPR; cc = (c - row * CPR) * 8; }
+            const int m = m0 + wr * G1_EROWS + row, n = n0 + cc;
+            if (m >= p.M || n >= p.N) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * G1_CLD + cc);
+            const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * G1_CLD + cc + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo, use_col_pre, col_pre0, col_pre1);
+        }
+        if (wr == 0) __syncthreads();
+    }
+}
+
 }  // namespace
+
+int imd_launch_gemm_dma128(const ConvGemmParams& p, hipStream_t s) {     // tile config 17
+    if (!imd_gemm_dma_supported(p)) return imd_set_error("gemm_dma128: needs a plain linear layer with K %% 64 == 0 and no K split (got K=%d taps=%d split=%d)", p.K, p.taps, p.split_k);
+    static bool attr_set[2] = {false, false};
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    const void* kern = h ? reinterpret_cast<const void*>(gemm_dma128_kernel<true>) : reinterpret_cast<const void*>(gemm_dma128_kernel<false>);
+    if (!attr_set[h]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS);
+        if (e != hipSuccess) return imd_set_error("gemm_dma128: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set[h] = true;
+    }
+    const long mt = (p.M + G1_BM - 1) / G1_BM, nt = (p.N + G1_BN - 1) / G1_BN;
+    if (h) hipLaunchKernelGGL(gemm_dma128_kernel<true>, dim3((unsigned)(mt * nt)), dim3(256), G1_LDS, s, p);
+    else hipLaunchKernelGGL(gemm_dma128_kernel<false>, dim3((unsigned)(mt * nt)), dim3(256), G1_LDS, s, p);
+    return imd_check_launch("gemm_dma128");
+}
 
 bool imd_gemm_dma_supported(const ConvGemmParams& p) {
     return p.taps == 1 && p.stride == 1 && !p.ups && p.Hin == p.Hout && p.Win == p.Wout && p.Cin == p.K && (p.K % GD_BK) == 0 &&

@@ -29,6 +29,7 @@ __device__ __forceinline__ void dma16_nonop(const v4i_t& rsrc, uint32_t lds_addr
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void dma_wait_keep2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }   // all but the 2 youngest pieces
 __device__ __forceinline__ void dma_wait_keep3() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }   // all but the 3 youngest pieces
+__device__ __forceinline__ void dma_wait_keep4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // all but the 4 youngest pieces
 __device__ __forceinline__ void dma_wait_keep5() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }   // all but the 5 youngest pieces
 __device__ __forceinline__ v4i_t raw_rsrc(const void* base, uint32_t bytes) {      // stride 0, raw addressing, wave-uniform by construction
     const uint64_t a = (uint64_t)base;

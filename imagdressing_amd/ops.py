@@ -232,7 +232,10 @@ def conv_gemm(
         GEMM_TRACE.append(dict(M=M, N=N, K=K, Cin=Cin, taps=taps, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride,
                                ups=int(ups), splittable=splittable, dtype=str(dt)))
     if cfg == -1 and split_k == 0:
-        ent = _gemm_table().get(f"{M},{N},{K},{taps},{stride},{int(ups)}")
+        # 3x3 convs are keyed WITH their output map as well (round 3): the same (M, N, K) occurs for different maps -- 2 images of
+        # 20x16 and 8 images of 10x8 are both 640 rows -- and the halo-patch kernel only takes maps at least 16 wide
+        key = f"{M},{N},{K},{taps},{stride},{int(ups)}"
+        ent = (_gemm_table().get(f"{key}|{Hout}x{Wout}") if taps == 9 else None) or _gemm_table().get(key)
         if ent is not None:
             if splittable:
                 cfg, split_k = ent["cfg"], ent["split"]
@@ -244,11 +247,11 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg in (12, 13, 14, 15) and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
-            if cfg == 16 and not lib.imd_gemm_dma_supported(C.byref(p)):
+            if cfg in (16, 17) and not lib.imd_gemm_dma_supported(C.byref(p)):
                 cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
-    if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and not ups and Wout >= PATCH_MIN_W and N >= 64 \
+    if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and Wout >= PATCH_MIN_W and N >= 64 \
             and lib.imd_conv_patch_supported(C.byref(p)):
         cfg = 5
     if split_k == 0:        # auto: K slices only where the tile grid cannot fill the chip

@@ -285,31 +285,34 @@ def test_row_qkv(ops, ln, dt):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 320, 320), (1000, 2560, 640), (77, 64, 768), (520, 1284, 1280), (2048 + 19, 520, 128)])
+@pytest.mark.parametrize("cfg", [16, 17])
 @DTS
-def test_linear_gemm_dma(ops, M, N, K, dt):
-    """tile config 16: 256 x 256 x 64 tiles staged by LDS-DMA (gemm_dma.hip) == x W^T + b, with the shared epilogues"""
+def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
+    """tile configs 16 (256 x 256 x 64, two stages) and 17 (128 x 128 x 32, three-stage ring, round 3): both operands by LDS-DMA
+    (gemm_dma.hip) == x W^T + b, with the shared epilogues"""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
     base = x.float() @ w.float().t() + b
-    assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=16), base, what="gemm_dma")
-    assert_close(ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=16), base + res.float(), what="gemm_dma + residual")
+    assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=cfg), base, what="gemm_dma")
+    assert_close(ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=cfg), base + res.float(), what="gemm_dma + residual")
     if N % 8 == 0:
-        gg = ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_GEGLU, cfg=16)
+        gg = ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_GEGLU, cfg=cfg)
         assert_close(gg, base[:, 0::2] * F.gelu(base[:, 1::2]), what="gemm_dma geglu")
-    one = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=16)
+    one = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=cfg)
     assert_close(one, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=0).float(), atol=2e-2 if dt == bf16 else 4e-3, what="gemm_dma vs tiled")
-    assert torch.equal(one, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=16)), "not deterministic"
+    assert torch.equal(one, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=cfg)), "not deterministic"
     with pytest.raises(ops.L.ImdError):
-        ops.linear(dev(rnd(1, 64, 72).to(dt)), dev(rnd(2, 64, 72).to(dt)), cfg=16)           # K % 64 != 0: refused
+        ops.linear(dev(rnd(1, 64, 72).to(dt)), dev(rnd(2, 64, 72).to(dt)), cfg=cfg)           # K % 64 != 0: refused
 
 
+@pytest.mark.parametrize("cfg", [16, 17])
 @DTS
-def test_gemm_dma_head_split(ops, dt):
+def test_gemm_dma_head_split(ops, dt, cfg):
     """head-split q / k / v epilogue through tile config 16 (the 32x32-level projection: 8 heads x 80)"""
     B, HW, Cc, H, D = 2, 300, 640, 8, 80
     DPK, DPV = ops.attn_padded_dims(D); LP = ops.pad64(HW)
     x = rnd(1, B * HW, Cc).to(dt); w = rnd(2, 3 * Cc, Cc, scale=Cc ** -0.5).to(dt)
     q = torch.zeros(B, H, HW, DPK, dtype=dt, device="cuda"); k = torch.zeros_like(q); vt = torch.zeros(B, H, DPV, LP, dtype=dt, device="cuda")
-    ops.conv_gemm(dev(x), dev(w), M=B * HW, N=3 * Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, cfg=16,
+    ops.conv_gemm(dev(x), dev(w), M=B * HW, N=3 * Cc, Cin=Cc, Hin=HW, Win=1, Hout=HW, Wout=1, cfg=cfg,
                   heads=dict(C=Cc, H=H, D=D, dests=[(q, 0, DPK, HW, 0.3), (k, 0, DPK, HW, 1.0), (vt, 1, DPV, LP, 1.0)]))
     ref = F.linear(x.float(), w.float()).view(B, HW, 3, H, D)
     assert_close(q[..., :D], 0.3 * ref[:, :, 0].permute(0, 2, 1, 3), what="Q")
@@ -398,6 +401,30 @@ def _halo_patch_case(ops, B, H, W, Cin, Cout, split, dt):
         assert int(ops.splitk_counters(out.device).abs().max()) == 0
     with pytest.raises(ops.L.ImdError):
         ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), stride=2, cfg=5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,split", [(1, 8, 8, 64, 64, 1), (2, 16, 16, 640, 640, 2), (1, 12, 18, 32, 320, 1), (2, 32, 32, 320, 132, 1)])
+@DTS
+def test_conv3x3_halo_patch_fused_upsample(ops, B, H, W, Cin, Cout, split, dt):
+    """Upsample2D (nearest 2x -> conv3x3) on the halo-patch kernel: the upsample is a source-pixel map of the LDS-DMA staging
+    (logical pixel >> 1), the zero halo applies to the upsampled map; ragged tiles, K slices; equals the gather kernel's fused form"""
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    b = rnd(3, Cout)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b, padding=1).permute(0, 2, 3, 1)
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), ups=True, cfg=5, split_k=split)
+    assert tuple(out.shape) == (B, 2 * H, 2 * W, Cout)
+    assert_close(out, ref, what="halo-patch conv with fused nearest-2x upsample")
+    gather = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), ups=True, cfg=0, split_k=1)
+    assert_close(out, gather.float(), what="halo-patch vs gather kernel (fused upsample)")
+    lib = ops.L.load()
+    ops.L.check(lib.imd_set_tuning(2, 23 | 512))          # the register-staged form has no upsample path: refused, not wrong
+    try:
+        with pytest.raises(ops.L.ImdError):
+            ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), ups=True, cfg=5, split_k=1)
+    finally:
+        ops.L.check(lib.imd_set_tuning(2, 23))
 
 
 @pytest.mark.parametrize("silu", [False, True])

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from imagdressing_amd import ops
 
-CFGS = [0, 4, 2, 1, 5, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]      # 12-15: row-resident kernels (K = 320 / 640 / 1280 linears, 320 -> 960 qkv), 16: 256^2 LDS-DMA tile kernel; refused elsewhere
+CFGS = [0, 4, 2, 1, 5, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17]      # 12-15: row-resident kernels (K = 320 / 640 / 1280 linears, 320 -> 960 qkv), 16: 256^2 LDS-DMA tile kernel; refused elsewhere
 SPLITS = [1, 2, 3, 4, 6, 8]
 
 
@@ -28,6 +28,8 @@ def collect_shapes(args, dt):
     uniq = {}
     for t in tr:
         key = f"{t['M']},{t['N']},{t['K']},{t['taps']},{t['stride']},{t['ups']}"
+        if t["taps"] == 9:           # (same M, N, K for different maps: see ops.conv_gemm)
+            key += f"|{t['Hout']}x{t['Wout']}"
         e = uniq.setdefault(key, dict(t, count=0, any_splittable=False, any_unsplittable=False))
         e["count"] += 1
         e["any_splittable"] |= t["splittable"]
@@ -67,7 +69,7 @@ def only_linear(args, shapes, dt):
         shipped = (ent["cfg"], ent["split"]) if t["any_splittable"] else (ent["cfg_nosplit"], 1)
         cands = {}
         for rep in range(2):
-            for cand in [shipped] + [(c, 1) for c in (0, 4, 9, 10, 11, 12, 13, 14, 15, 16) if (c, 1) != shipped]:
+            for cand in [shipped] + [(c, 1) for c in (0, 4, 9, 10, 11, 12, 13, 14, 15, 16, 17) if (c, 1) != shipped]:
                 try:
                     us = time_candidate(t, cand[0], cand[1], dt, args.iters)
                 except Exception:          # noqa
@@ -104,6 +106,7 @@ def main():
     ap.add_argument("--merge", action="store_true", help="start from the shipped table and add / overwrite only the traced shapes")
     ap.add_argument("--skip-known", action="store_true", help="with --merge: leave shapes that the shipped table already holds alone")
     ap.add_argument("--quick", action="store_true", help="one repeat, K splits {1, 2, 4}")
+    ap.add_argument("--keep-margin", type=float, default=0.0, help="with --merge: keep a shape's shipped choice unless the winner is faster by this fraction")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--out", default="gpurun_out/gemm_tuning.json")
@@ -128,8 +131,8 @@ def main():
     if args.only_conv3x3:
         with open(os.path.join(os.path.dirname(os.path.abspath(ops.__file__)), "gemm_tuning.json")) as f:
             result = json.load(f).get("shapes", {})
-        shapes = {k: t for k, t in shapes.items() if t["taps"] == 9 and t["stride"] == 1 and not t["ups"] and t["Cin"] % 32 == 0}
-        cfgs = [0, 4, 5]
+        shapes = {k: t for k, t in shapes.items() if t["taps"] == 9 and t["stride"] == 1 and t["Cin"] % 32 == 0}      # (round 3: fused-upsample convs too)
+        cfgs = [0, 4, 5, 9, 10]
     total_before = total_after = 0.0
     for key, t in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
         flops = 2.0 * t["M"] * t["N"] * t["K"]
@@ -147,6 +150,14 @@ def main():
                     cands.setdefault((cfg, split), []).append(us)
         best = min(cands, key=lambda k: min(cands[k]))
         best_ns = min((k for k in cands if k[1] == 1), key=lambda k: min(cands[k]))
+        old = result.get(key) if args.keep_margin > 0 else None
+        if old is not None:          # hysteresis against timing noise: a shipped choice stays unless the winner beats it by the margin
+            sh = (old["cfg"], old["split"]) if t["any_splittable"] else (old["cfg_nosplit"], 1)
+            if sh in cands and min(cands[best]) > (1.0 - args.keep_margin) * min(cands[sh]):
+                best = sh
+            shn = (old["cfg_nosplit"], 1)
+            if shn in cands and min(cands[best_ns]) > (1.0 - args.keep_margin) * min(cands[shn]):
+                best_ns = shn
         auto_cfg = ops.L.load().imd_conv_gemm_auto_cfg(t["M"], t["N"])
         auto_split = ops.L.load().imd_conv_gemm_auto_split(t["M"], t["N"], t["K"], auto_cfg) if t["any_splittable"] else 1
         auto_us = min(cands.get((auto_cfg, auto_split), cands.get((auto_cfg, 1), [float("nan")])))
