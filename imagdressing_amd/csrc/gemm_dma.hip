@@ -162,7 +162,12 @@ constexpr int G1_CLD = G1_BN + 4, G1_EROWS = 64;
 constexpr int G1_LDS = G1_NST * G1_STAGE;                  // 49152 >= 64 x 132 x 4
 static_assert(G1_LDS >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");
 
-template <bool F16>
+// GATHER (tile config 18): the A operand is the implicit im2col matrix of a 3x3 convolution (stride 1 | 2, zero halo, optional fused
+// nearest-2x upsample, Cin % 32 == 0) -- a K tile is one tap x 32 channels (tap-inner order: consecutive tiles are neighbouring
+// taps of the same channels), an A row's 64 bytes are the 32 channels of ONE input pixel, and the per-lane DMA offset is
+// recomputed per tile from the row's top-left tap position; halo pixels are out-of-range offsets.  Serves the maps the halo-patch
+// kernel cannot tile (8 x 8) and the stride-2 convs.
+template <bool F16, bool GATHER>
 __global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParams p) {
     using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -176,26 +181,60 @@ __global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParam
     int tile_m, tile_n;
     xcd_tile_order(p.flags, (p.M + G1_BM - 1) / G1_BM, n_tiles, tile_m, tile_n);
     const int m0 = tile_m * G1_BM, n0 = tile_n * G1_BN;
-    const int nk = p.K / G1_BK;
+    // K range of this slice (split-K: blockIdx.y; fp32 slabs + the fixed-order finish launch of conv_gemm.hip)
+    const int nk_total = p.K / G1_BK;              // (GATHER: 9 taps x Cin / 32 channel chunks)
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    const int kt0 = blockIdx.y * per;
+    const int nk = max(0, min(nk_total, kt0 + per) - kt0);
 
     // a stage = 16 pieces of 1 KB (16 rows x 64 B each): pieces 0..7 activation rows, 8..15 weight rows; wave w issues pieces
     // w, w + 4 (activations) and 8 + w, 12 + w (weights)
     const v4i_t ds_x = raw_rsrc(p.x, p.x_bytes), ds_w = raw_rsrc(p.w, p.w_bytes);
     uint32_t soff[4];
+    int g_base[2] = {-1, -1}, g_y0[2] = {0, 0}, g_x0[2] = {0, 0}, g_pc[2] = {0, 0};        // GATHER: per A piece (row) of this lane
+    const int Hl = p.ups ? p.Hin * 2 : p.Hin, Wl = p.ups ? p.Win * 2 : p.Win;              // logical (post-upsample) input map
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int id = (j & 1) * 4 + wave;                    // piece inside its operand tile
         const int q = id * 64 + lane, row = q >> 2, pc = (q & 3) ^ ((row >> 2) & 3);
         if (j >= 2) soff[j] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + pc * 8) * 2) : OOB;
-        else soff[j] = (m0 + row < p.M) ? (uint32_t)(((size_t)(m0 + row) * p.x_pix_stride + pc * 8) * 2) : OOB;
+        else if (!GATHER) soff[j] = (m0 + row < p.M) ? (uint32_t)(((size_t)(m0 + row) * p.x_pix_stride + pc * 8) * 2) : OOB;
+        else {
+            soff[j] = OOB;
+            const int m = m0 + row;
+            if (m < p.M) {
+                const int HWo = p.Hout * p.Wout, pad = p.pad_br_only ? 0 : 1;
+                const int bi = m / HWo, rem = m - bi * HWo, oy = rem / p.Wout, ox = rem - oy * p.Wout;
+                g_base[j] = bi * p.Hin * p.Win; g_y0[j] = oy * p.stride - pad; g_x0[j] = ox * p.stride - pad; g_pc[j] = pc * 8;
+            }
+        }
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int nchunk = GATHER ? p.Cin / G1_BK : 1;
     auto stage = [&](int kt, int slot) {                      // (tiles past the end: zero-fill pieces keep the counted waits uniform)
         const uint32_t base = lds0 + (uint32_t)(slot * G1_STAGE);
+        const int kg = kt0 + kt;
+        int ky = 0, kx = 0, ci = 0;
+        uint32_t wk = (uint32_t)(kg * G1_BK * 2);             // byte offset of the tile inside a weight row
+        if (GATHER) {                                         // tap-inner tile order: tile kg -> (channel chunk kg / 9, tap kg % 9)
+            const int c = kg / 9, tap = kg - 9 * c;
+            ky = tap / 3; kx = tap - 3 * ky; ci = c * G1_BK;
+            wk = (uint32_t)((tap * p.Cin + ci) * 2);
+            (void)nchunk;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int id = (j & 1) * 4 + wave + (j >= 2 ? 8 : 0);
-            dma16(j >= 2 ? ds_w : ds_x, base + (uint32_t)id * 1024u, (soff[j] == OOB || kt >= nk) ? OOB : soff[j] + (uint32_t)(kt * G1_BK * 2));
+            uint32_t off;
+            if (j >= 2) off = (soff[j] == OOB || kt >= nk) ? OOB : soff[j] + wk;
+            else if (!GATHER) off = (soff[j] == OOB || kt >= nk) ? OOB : soff[j] + wk;
+            else {
+                const int iy = g_y0[j] + ky, ix = g_x0[j] + kx;
+                const bool ok = kt < nk && g_base[j] >= 0 && (unsigned)iy < (unsigned)Hl && (unsigned)ix < (unsigned)Wl;
+                const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                off = ok ? (uint32_t)((g_base[j] + sy * p.Win + sx) * p.x_pix_stride + ci + g_pc[j]) * 2u : OOB;
+            }
+            dma16(j >= 2 ? ds_w : ds_x, base + (uint32_t)id * 1024u, off);
         }
     };
 
@@ -248,9 +287,10 @@ __global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParam
     constexpr int CPR = G1_BN / 8;
     constexpr int CHUNKS = G1_EROWS * CPR;
     const bool colmajor = p.mode == OUT_HEADS;
+    float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)blockIdx.y * p.M * p.N : nullptr;
     float4 col_pre0 = make_float4(0, 0, 0, 0), col_pre1 = col_pre0;
     bool use_col_pre = false;
-    if (!colmajor && (p.bias || p.rowvec)) {
+    if (!colmajor && slab == nullptr && (p.bias || p.rowvec)) {
         const int bi_lo = m0 / HWo, bi_hi = (min(m0 + G1_BM, p.M) - 1) / HWo;
         const int n = n0 + (tid % CPR) * 8;
         if ((p.rowvec == nullptr || bi_lo == bi_hi) && n < p.N) {
@@ -280,8 +320,12 @@ __global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParam
             if (m >= p.M || n >= p.N) continue;
             const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * G1_CLD + cc);
             const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * G1_CLD + cc + 4);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo, use_col_pre, col_pre0, col_pre1);
+            if (slab) {                         // raw fp32 partial tile -> slab [split][M][N]
+                slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, false);
+            } else {
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo, use_col_pre, col_pre0, col_pre1);
+            }
         }
         if (wr == 0) __syncthreads();
     }
@@ -289,20 +333,38 @@ __global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParam
 
 }  // namespace
 
-int imd_launch_gemm_dma128(const ConvGemmParams& p, hipStream_t s) {     // tile config 17
-    if (!imd_gemm_dma_supported(p)) return imd_set_error("gemm_dma128: needs a plain linear layer with K %% 64 == 0 and no K split (got K=%d taps=%d split=%d)", p.K, p.taps, p.split_k);
+bool imd_conv_dma_supported(const ConvGemmParams& p) {       // tile config 18: 3x3 convs through the gathering form of the 128 x 128 x 32 DMA kernel
+    return p.taps == 9 && (p.stride == 1 || p.stride == 2) && (p.Cin % G1_BK) == 0 && p.K == 9 * p.Cin && p.gn_a == nullptr &&
+           (p.x_pix_stride % 8) == 0 && (!p.ups || p.stride == 1);
+}
+
+template <bool GATHER>
+static int launch_dma128(const ConvGemmParams& p, hipStream_t s, const char* what) {
     static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
-    const void* kern = h ? reinterpret_cast<const void*>(gemm_dma128_kernel<true>) : reinterpret_cast<const void*>(gemm_dma128_kernel<false>);
+    typedef void (*kern_t)(const ConvGemmParams);
+    const kern_t kern = h ? gemm_dma128_kernel<true, GATHER> : gemm_dma128_kernel<false, GATHER>;
     if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS);
-        if (e != hipSuccess) return imd_set_error("gemm_dma128: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS);
+        if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
         attr_set[h] = true;
     }
     const long mt = (p.M + G1_BM - 1) / G1_BM, nt = (p.N + G1_BN - 1) / G1_BN;
-    if (h) hipLaunchKernelGGL(gemm_dma128_kernel<true>, dim3((unsigned)(mt * nt)), dim3(256), G1_LDS, s, p);
-    else hipLaunchKernelGGL(gemm_dma128_kernel<false>, dim3((unsigned)(mt * nt)), dim3(256), G1_LDS, s, p);
-    return imd_check_launch("gemm_dma128");
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(256), G1_LDS, s, p);
+    return imd_check_launch(what);
+}
+
+int imd_launch_gemm_dma128(const ConvGemmParams& p_in, hipStream_t s) {     // tile config 17 (plain linears) / 18 (3x3 convs); K slices allowed
+    ConvGemmParams p = p_in;
+    p.splitk_counters = nullptr;               // (the in-kernel reduction lives in the register-staged kernels only)
+    if (p.taps == 9) {
+        if (!imd_conv_dma_supported(p)) return imd_set_error("conv_dma: needs a 3x3 convolution with Cin %% 32 == 0 (got Cin=%d stride=%d)", p.Cin, p.stride);
+        return launch_dma128<true>(p, s, "conv_dma128");
+    }
+    ConvGemmParams p1 = p;
+    p1.split_k = 1;
+    if (!imd_gemm_dma_supported(p1)) return imd_set_error("gemm_dma128: needs a plain linear layer with K %% 64 == 0 (got K=%d taps=%d)", p.K, p.taps);
+    return launch_dma128<false>(p, s, "gemm_dma128");
 }
 
 bool imd_gemm_dma_supported(const ConvGemmParams& p) {

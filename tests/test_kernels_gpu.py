@@ -83,7 +83,8 @@ def test_linear_epilogues(ops, dt):
 
 
 @DTS
-@pytest.mark.parametrize("M,N,K,split,cfg", [(512, 1280, 11520, 6, 0), (200, 320, 2304, 3, 2), (2048, 132, 4096, 4, 1), (64, 64, 8192, 8, -1), (300, 640, 2560, 5, 6), (130, 64, 4096, 7, 7), (600, 384, 2048, 3, 9), (520, 520, 1024, 2, 10)])
+@pytest.mark.parametrize("M,N,K,split,cfg", [(512, 1280, 11520, 6, 0), (200, 320, 2304, 3, 2), (2048, 132, 4096, 4, 1), (64, 64, 8192, 8, -1), (300, 640, 2560, 5, 6), (130, 64, 4096, 7, 7), (600, 384, 2048, 3, 9), (520, 520, 1024, 2, 10),
+                                                  (512, 1280, 5120, 3, 17), (300, 132, 2048, 4, 17)])
 def test_linear_split_k(ops, M, N, K, split, cfg, dt):
     """K slices into fp32 slabs + fixed-order finish kernel == unsplit result (bias + residual + SiLU epilogue)."""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
@@ -346,12 +347,14 @@ def pack_conv(w):  # [Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin]
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 18])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
     (2, 16, 16, 64, 64, 1, False), (1, 12, 20, 32, 320, 1, False), (2, 16, 16, 64, 128, 2, False),
     (1, 8, 8, 64, 64, 1, True), (1, 9, 7, 8, 320, 1, False), (3, 6, 6, 320, 4, 1, False)])
 @DTS
 def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups, dt):
+    if cfg == 18 and Cin % 32:          # the gathering LDS-DMA form moves 32-channel pieces
+        pytest.skip("tile config 18 needs Cin % 32 == 0")
     x = rnd(1, B, Cin, H, W).to(dt)
     w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
     b = rnd(3, Cout)
@@ -401,6 +404,23 @@ def _halo_patch_case(ops, B, H, W, Cin, Cout, split, dt):
         assert int(ops.splitk_counters(out.device).abs().max()) == 0
     with pytest.raises(ops.L.ImdError):
         ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), dev(b), stride=2, cfg=5)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,split", [(8, 8, 8, 1280, 1280, 1, 6), (8, 16, 16, 640, 128, 2, 3), (2, 8, 8, 2560, 132, 1, 8),
+                                                       (1, 17, 9, 64, 64, 2, 1)])
+@DTS
+def test_conv3x3_dma_gather_split_k(ops, B, H, W, Cin, Cout, stride, split, dt):
+    """tile config 18 (3x3 conv gathered tile by tile into the three-stage LDS-DMA ring of gemm_dma.hip) on the maps the halo-patch
+    kernel cannot tile -- 8 x 8, stride 2, odd sizes -- with K slices and the full epilogue"""
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    b = rnd(3, Cout)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1, stride=stride).permute(0, 2, 3, 1)
+    res = rnd(5, *ref.shape).to(dt)
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), stride=stride, res=dev(res), cfg=18, split_k=split)
+    assert_close(out, ref + res.float(), what=f"conv_dma split={split}")
+    assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), stride=stride, res=dev(res), cfg=18, split_k=split)), "not deterministic"
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,split", [(1, 8, 8, 64, 64, 1), (2, 16, 16, 640, 640, 2), (1, 12, 18, 32, 320, 1), (2, 32, 32, 320, 132, 1)])
