@@ -23,10 +23,16 @@ __host__ __device__ inline int gn_pix_per_chunk(int B, int HW, int C) {
     const int vpp = C / 8;
     const int cols = vpp < GN_THREADS ? vpp : GN_THREADS;
     const int plan = GN_THREADS / cols;
-    int ppc = (int)(((long)B * HW + 1023) / 1024);
+#ifndef GN_TARGET_BLOCKS
+#define GN_TARGET_BLOCKS 512      // A/B on one box (profiles/r3z_gn_ab.txt): 2048 -> +1.6 %, 1024 -> 0, 512 -> -0.5 %, 128 -> +1.3 % of the step
+#endif
+#ifndef GN_MAX_PPC
+#define GN_MAX_PPC 128
+#endif
+    int ppc = (int)(((long)B * HW + GN_TARGET_BLOCKS - 1) / GN_TARGET_BLOCKS);
     ppc = (ppc + plan - 1) / plan * plan;
     if (ppc < 2 * plan) ppc = 2 * plan;
-    if (ppc > 64) ppc = 64;
+    if (ppc > GN_MAX_PPC) ppc = GN_MAX_PPC;
     return ppc;
 }
 __host__ __device__ inline int gn_chunks(int B, int HW, int C) {
