@@ -360,7 +360,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 6: *bm = 64; *bn = 320; return 0;
         case 9: *bm = 256; *bn = 128; return 0;
         case 10: case 16: *bm = 256; *bn = 256; return 0;
-        case 17: case 18: *bm = 128; *bn = 128; return 0;
+        case 17: case 18: case 19: case 20: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
         default: return 1;
     }
@@ -478,10 +478,11 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 14: return imd_launch_row_linear_k1280(p, 0, 0.f, s); // row-resident 4-way split-K kernel (row_linear_k1280.hip): K = 1280, N % 160 == 0
         case 16: return imd_launch_gemm_dma(p, s);                 // 256 x 256 x 64 LDS-DMA tile kernel for the large linears (gemm_dma.hip)
         case 15: return imd_launch_row_qkv(p, 0, 0.f, s);          // row-resident q/k/v projection of a 320-channel block (row_qkv.hip)
-        case 17: case 18: {   // 128 x 128 x 32 LDS-DMA tiles, 3-stage ring, 3 workgroups / CU (gemm_dma.hip; 17: plain linears, 18: 3x3 convs gathered per tile); K slices finish like the tiled kernels'
-            if ((cfg == 18) != (p.taps == 9)) return imd_set_error("conv_gemm: tile config %d does not take taps = %d", cfg, p.taps);
+        case 17: case 18: case 19: case 20: {   // 128 x 128 x 32 LDS-DMA tiles (gemm_dma.hip): 17 / 18 three-stage ring, 3 workgroups / CU; 19 / 20 four stages, 2 / CU;
+                                                // 17, 19: plain linears, 18, 20: 3x3 convs gathered per tile; K slices finish like the tiled kernels'
+            if ((cfg == 18 || cfg == 20) != (p.taps == 9)) return imd_set_error("conv_gemm: tile config %d does not take taps = %d", cfg, p.taps);
             p.splitk_counters = nullptr;
-            int rc = imd_launch_gemm_dma128(p, s);
+            int rc = imd_launch_gemm_dma128(p, cfg >= 19 ? 4 : 3, s);
             if (rc || p.split_k <= 1) return rc;
             const long chunks = (long)p.M * ((p.N + 7) / 8);
             long blocks = (chunks + 255) / 256;

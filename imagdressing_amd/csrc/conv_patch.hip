@@ -213,13 +213,23 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
             w_src[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8) * 2) : OOB;
         }
         auto dma_patch = [&](int c, int buf) {
+#ifdef PATCH_T_NODMA
+            if (c > c_begin) return;
+#endif
 #pragma unroll
             for (int i = 0; i < 3; ++i)
                 dma16(dx, smem_base + buf * AB_D + (wv * 3 + i) * 1024, (a_src[i] != OOB && c < c_end) ? a_src[i] + (uint32_t)(c * CK * 2) : OOB);
         };
         auto dma_w = [&](int it, int ring) {
             const int cq = it / 9;
+#ifdef PATCH_T_WHOT
+            const uint32_t koff = 0; (void)cq;
+#else
             const uint32_t koff = (uint32_t)(((it - cq * 9) * p.Cin + (c_begin + cq) * CK) * 2);
+#endif
+#ifdef PATCH_T_NODMA
+            if (it >= 2) return;
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 dma16(dw, smem_base + 2 * AB_D + ring * WB_D + (wv * 2 + i) * 1024, (w_src[i] != OOB && it < total) ? w_src[i] + koff : OOB);
@@ -249,7 +259,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
             for (int t = 0; t < 9; ++t) {                  // 9 taps = 3 turns of the weight ring: ring slots are compile-time
                 dma_w(cc * 9 + t + 2, (t + 2) % 3);
                 if (t == 5) dma_patch(c_begin + cc + 1, ab ^ 1);       // (always 3 pieces, zeros past the last chunk: the counted waits rely on it)
+#ifdef PATCH_T_NOMFMA
+                if (wave_live && p.M < 0) {
+#else
                 if (wave_live) {
+#endif
                     const char* As = smem + ab * AB_D;
                     const char* Ws = smem + 2 * AB_D + (t % 3) * WB_D;
                     int xa[2];
@@ -274,7 +288,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
                 // the next tap's weight pieces have landed: everything but this tap's two pieces (and, at taps 5 and 6, the three
                 // patch pieces issued behind them at tap 5) may stay in flight
                 if (t == 5 || t == 6) dma_wait_keep5(); else dma_wait_keep2();
+#ifndef PATCH_T_NOBAR
                 __syncthreads();
+#endif
             }
         }
         dma_wait();                  // zero-fill pieces past the end are still landing: the epilogue reuses this LDS

@@ -156,20 +156,24 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const ConvGemmParams p
 // four 1-KB pieces per tile), unpadded 64-byte rows with piece c of row r at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128),
 // no staging registers, no VGPR -> LDS stores.  Epilogue = conv_gemm.hip's.
 // ---------------------------------------------------------------------------------------------------------------------------
-constexpr int G1_BM = 128, G1_BN = 128, G1_BK = 32, G1_NST = 3;
+// NST = 4 (tile configs 19 / 20; round 3): a FOUR-stage ring, 64 KB -> two workgroups per CU with three tiles of lead instead of three
+// workgroups with two.  Same bytes in flight per CU, but each workgroup's wait is one tile further behind its issue: -8...-22 % on the
+// large linears on one box (profiles/r3ab_ring_depth_big_linears.txt; five stages = one workgroup per CU is slower than either).
+constexpr int G1_BM = 128, G1_BN = 128, G1_BK = 32;
+template <int N> __device__ __forceinline__ void dma_wait_keep_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int G1_STAGE = (G1_BM + G1_BN) * G1_BK * 2;      // 16384
 constexpr int G1_CLD = G1_BN + 4, G1_EROWS = 64;
-constexpr int G1_LDS = G1_NST * G1_STAGE;                  // 49152 >= 64 x 132 x 4
-static_assert(G1_LDS >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");
+static_assert(3 * G1_STAGE >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");
 
 // GATHER (tile config 18): the A operand is the implicit im2col matrix of a 3x3 convolution (stride 1 | 2, zero halo, optional fused
 // nearest-2x upsample, Cin % 32 == 0) -- a K tile is one tap x 32 channels (tap-inner order: consecutive tiles are neighbouring
 // taps of the same channels), an A row's 64 bytes are the 32 channels of ONE input pixel, and the per-lane DMA offset is
 // recomputed per tile from the row's top-left tap position; halo pixels are out-of-range offsets.  Serves the maps the halo-patch
 // kernel cannot tile (8 x 8) and the stride-2 convs.
-template <bool F16, bool GATHER>
-__global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParams p) {
+template <bool F16, bool GATHER, int G1_NST>
+__global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(const ConvGemmParams p) {
     using E = El<F16>;
+    constexpr int G1_KEEP = (G1_NST - 2) * 4;                  // pieces of the younger tiles that may stay in flight at the per-tile wait
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -251,14 +255,14 @@ __global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParam
     const int fo = col * 64 + ((hi ^ ((col >> 2) & 3)) << 4);
     const bool wave_live = n0 + wn0 < p.N && m0 + wm0 < p.M;
 
-    stage(0, 0);
-    stage(1, 1);
-    dma_wait_keep4();
+#pragma unroll
+    for (int t = 0; t < G1_NST - 1; ++t) stage(t, t);
+    dma_wait_keep_n<G1_KEEP>();
     __syncthreads();
     int slot = 0;
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
-        stage(kt + 2, slot == 0 ? 2 : slot - 1);              // slot (kt + 2) % 3: last read at tile kt - 1, everybody is past that barrier
+        stage(kt + G1_NST - 1, slot == 0 ? G1_NST - 1 : slot - 1);   // slot (kt - 1) % NST: last read at tile kt - 1, everybody is past that barrier
         if (wave_live) {
             const char* Xs = smem + slot * G1_STAGE + wm0 * 64;
             const char* Ws = smem + slot * G1_STAGE + G1_BM * 64 + wn0 * 64;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256, 3) void gemm_dma128_kernel(const ConvGemmParam
             }
         }
         slot = slot == G1_NST - 1 ? 0 : slot + 1;
-        dma_wait_keep4();              // tile kt + 1 has landed (this wave's pieces; tile kt + 2's four stay in flight) ...
+        dma_wait_keep_n<G1_KEEP>();    // tile kt + 1 has landed (this wave's pieces; the younger tiles' stay in flight) ...
         __syncthreads();               // ... and everybody's
     }
     dma_wait();                        // zero-fill pieces past the end: the epilogue reuses this LDS
@@ -338,33 +342,36 @@ bool imd_conv_dma_supported(const ConvGemmParams& p) {       // tile config 18: 
            (p.x_pix_stride % 8) == 0 && (!p.ups || p.stride == 1);
 }
 
-template <bool GATHER>
+template <bool GATHER, int NST>
 static int launch_dma128(const ConvGemmParams& p, hipStream_t s, const char* what) {
     static bool attr_set[2] = {false, false};
+    constexpr int LDS = NST * G1_STAGE;        // 49152 (three stages) | 65536 (four)
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
-    const kern_t kern = h ? gemm_dma128_kernel<true, GATHER> : gemm_dma128_kernel<false, GATHER>;
+    const kern_t kern = h ? gemm_dma128_kernel<true, GATHER, NST> : gemm_dma128_kernel<false, GATHER, NST>;
     if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G1_LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
         attr_set[h] = true;
     }
     const long mt = (p.M + G1_BM - 1) / G1_BM, nt = (p.N + G1_BN - 1) / G1_BN;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(256), G1_LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(256), LDS, s, p);
     return imd_check_launch(what);
 }
 
-int imd_launch_gemm_dma128(const ConvGemmParams& p_in, hipStream_t s) {     // tile config 17 (plain linears) / 18 (3x3 convs); K slices allowed
+// tile configs 17 / 19 (plain linears, three / four ring stages) and 18 / 20 (3x3 convs, likewise); K slices allowed
+int imd_launch_gemm_dma128(const ConvGemmParams& p_in, int stages, hipStream_t s) {
     ConvGemmParams p = p_in;
     p.splitk_counters = nullptr;               // (the in-kernel reduction lives in the register-staged kernels only)
+    if (stages != 3 && stages != 4) return imd_set_error("gemm_dma128: %d ring stages (3 | 4)", stages);
     if (p.taps == 9) {
         if (!imd_conv_dma_supported(p)) return imd_set_error("conv_dma: needs a 3x3 convolution with Cin %% 32 == 0 (got Cin=%d stride=%d)", p.Cin, p.stride);
-        return launch_dma128<true>(p, s, "conv_dma128");
+        return stages == 3 ? launch_dma128<true, 3>(p, s, "conv_dma128") : launch_dma128<true, 4>(p, s, "conv_dma128 (4 stages)");
     }
     ConvGemmParams p1 = p;
     p1.split_k = 1;
     if (!imd_gemm_dma_supported(p1)) return imd_set_error("gemm_dma128: needs a plain linear layer with K %% 64 == 0 (got K=%d taps=%d)", p.K, p.taps);
-    return launch_dma128<false>(p, s, "gemm_dma128");
+    return stages == 3 ? launch_dma128<false, 3>(p, s, "gemm_dma128") : launch_dma128<false, 4>(p, s, "gemm_dma128 (4 stages)");
 }
 
 bool imd_gemm_dma_supported(const ConvGemmParams& p) {

@@ -247,9 +247,9 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg in (12, 13, 14, 15) and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
-            if cfg in (16, 17) and not lib.imd_gemm_dma_supported(C.byref(p)):
+            if cfg in (16, 17, 19) and not lib.imd_gemm_dma_supported(C.byref(p)):
                 cfg, split_k = -1, 0
-            if cfg == 18 and (taps != 9 or Cin % 32 or stride not in (1, 2) or gn is not None):
+            if cfg in (18, 20) and (taps != 9 or Cin % 32 or stride not in (1, 2) or gn is not None):
                 cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)

@@ -178,7 +178,8 @@ int imd_device_check(int device);
  * 7: 64x64x32 / 4 in flight, 8: 128x128x32 / 4 in flight, 9: 256x128x32, 10: 256x256x32 and 11: 128x320x64 (8-wave workgroups:
  * fewer operand bytes fetched per MFMA for the wide projections; 11 covers N = 320 k with full-width row blocks); 12..15: row-resident
  * kernels; 16: 256x256x64 and 17: 128x128x32 with a three-stage ring, both operands staged by LDS-DMA (plain linear layers, K % 64 == 0);
- * 18: the gathering form of 17 for 3x3 convolutions (stride 1 | 2, Cin % 32 == 0; K slices allowed for 17 and 18).
+ * 18: the gathering form of 17 for 3x3 convolutions (stride 1 | 2, Cin % 32 == 0; K slices allowed for 17 and 18);
+ * 19 / 20: 17 / 18 with a four-stage ring (64 KB, two workgroups per CU, three tiles of lead).
  * Results are identical up to fp32 summation order. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);

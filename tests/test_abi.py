@@ -70,7 +70,7 @@ def test_pure_queries_work_without_gpu(lib):
     assert lib.imd_attn_padded_dims(160, ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value, b.value) == (160, 160)
     assert lib.imd_attn_padded_dims(33, ctypes.byref(a), ctypes.byref(b)) != 0
     assert b"unsupported head dim" in lib.imd_last_error()
-    assert lib.imd_groupnorm_workspace_floats(8, 4096, 320, 32) == 8 * 128 * 32 * 2 + 2 * 8 * 320      # 32-pixel chunk partials + coefficients
+    assert lib.imd_groupnorm_workspace_floats(8, 4096, 320, 32) == 8 * 64 * 32 * 2 + 2 * 8 * 320       # 64-pixel chunk partials (512-block target) + coefficients
     assert lib.imd_groupnorm_workspace_floats(8, 64, 1280, 32) == 8 * 16 * 32 * 2 + 2 * 8 * 1280         # 4-pixel chunks at 8x8
     assert lib.imd_conv_gemm_auto_cfg(32768, 320) in (0, 1, 2, 4)
 

@@ -286,10 +286,10 @@ def test_row_qkv(ops, ln, dt):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 320, 320), (1000, 2560, 640), (77, 64, 768), (520, 1284, 1280), (2048 + 19, 520, 128)])
-@pytest.mark.parametrize("cfg", [16, 17])
+@pytest.mark.parametrize("cfg", [16, 17, 19])
 @DTS
 def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
-    """tile configs 16 (256 x 256 x 64, two stages) and 17 (128 x 128 x 32, three-stage ring, round 3): both operands by LDS-DMA
+    """tile configs 16 (256 x 256 x 64, two stages), 17 and 19 (128 x 128 x 32, three- / four-stage ring, round 3): both operands by LDS-DMA
     (gemm_dma.hip) == x W^T + b, with the shared epilogues"""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
     base = x.float() @ w.float().t() + b
@@ -305,7 +305,7 @@ def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
         ops.linear(dev(rnd(1, 64, 72).to(dt)), dev(rnd(2, 64, 72).to(dt)), cfg=cfg)           # K % 64 != 0: refused
 
 
-@pytest.mark.parametrize("cfg", [16, 17])
+@pytest.mark.parametrize("cfg", [16, 17, 19])
 @DTS
 def test_gemm_dma_head_split(ops, dt, cfg):
     """head-split q / k / v epilogue through tile config 16 (the 32x32-level projection: 8 heads x 80)"""
@@ -408,9 +408,10 @@ def _halo_patch_case(ops, B, H, W, Cin, Cout, split, dt):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,split", [(8, 8, 8, 1280, 1280, 1, 6), (8, 16, 16, 640, 128, 2, 3), (2, 8, 8, 2560, 132, 1, 8),
                                                        (1, 17, 9, 64, 64, 2, 1)])
+@pytest.mark.parametrize("cfg", [18, 20])
 @DTS
-def test_conv3x3_dma_gather_split_k(ops, B, H, W, Cin, Cout, stride, split, dt):
-    """tile config 18 (3x3 conv gathered tile by tile into the three-stage LDS-DMA ring of gemm_dma.hip) on the maps the halo-patch
+def test_conv3x3_dma_gather_split_k(ops, B, H, W, Cin, Cout, stride, split, dt, cfg):
+    """tile configs 18 / 20 (3x3 conv gathered tile by tile into the three- / four-stage LDS-DMA ring of gemm_dma.hip) on the maps the halo-patch
     kernel cannot tile -- 8 x 8, stride 2, odd sizes -- with K slices and the full epilogue"""
     x = rnd(1, B, Cin, H, W).to(dt)
     w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
@@ -418,9 +419,9 @@ def test_conv3x3_dma_gather_split_k(ops, B, H, W, Cin, Cout, stride, split, dt):
     ref = F.conv2d(x.float(), w.float(), b, padding=1, stride=stride).permute(0, 2, 3, 1)
     res = rnd(5, *ref.shape).to(dt)
     xd = dev(x.permute(0, 2, 3, 1).contiguous())
-    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), stride=stride, res=dev(res), cfg=18, split_k=split)
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), stride=stride, res=dev(res), cfg=cfg, split_k=split)
     assert_close(out, ref + res.float(), what=f"conv_dma split={split}")
-    assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), stride=stride, res=dev(res), cfg=18, split_k=split)), "not deterministic"
+    assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), stride=stride, res=dev(res), cfg=cfg, split_k=split)), "not deterministic"
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,split", [(1, 8, 8, 64, 64, 1), (2, 16, 16, 640, 640, 2), (1, 12, 18, 32, 320, 1), (2, 32, 32, 320, 132, 1)])
