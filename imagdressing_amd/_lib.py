@@ -77,7 +77,7 @@ class DdimParams(C.Structure):
         ("sqrt_a_prev", C.c_float), ("sqrt_1m_a_prev", C.c_float),
         ("mask", C.c_void_p), ("z_img", C.c_void_p), ("noise", C.c_void_p),
         ("sqrt_a_next", C.c_float), ("sqrt_1m_a_next", C.c_float), ("dtype", C.c_int),
-        ("coefs", C.c_void_p),
+        ("coefs", C.c_void_p), ("var_noise", C.c_void_p), ("sigma", C.c_float),
     ]
 
 
@@ -134,8 +134,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if lib.imd_abi_version() != 5:
-            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 5")
+        if lib.imd_abi_version() != 6:
+            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 6")
         _lib = lib
     return _lib
 

@@ -31,7 +31,11 @@ __global__ __launch_bounds__(256) void ddim_cfg_step_kernel(const DdimParams p) 
         const float c[4] = {ec.x, ec.y, ec.z, ec.w};
         const float u[4] = {eu.x, eu.y, eu.z, eu.w};
         float mk = 1.f;
-        float zi[4] = {0, 0, 0, 0}, nz[4] = {0, 0, 0, 0};
+        float zi[4] = {0, 0, 0, 0}, nz[4] = {0, 0, 0, 0}, vn[4] = {0, 0, 0, 0};
+        if (p.var_noise) {                                 // stochastic DDIM (eta > 0): sigma * noise, added before the blend
+            const float4 n = reinterpret_cast<const float4*>(p.var_noise)[i];
+            vn[0] = p.sigma * n.x; vn[1] = p.sigma * n.y; vn[2] = p.sigma * n.z; vn[3] = p.sigma * n.w;
+        }
         if (p.mask) {
             mk = p.mask[i];
             const float4 a = reinterpret_cast<const float4*>(p.z_img)[i];
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(256) void ddim_cfg_step_kernel(const DdimParams p) 
         for (int e = 0; e < 4; ++e) {
             const float eps = u[e] + p.guidance * (c[e] - u[e]);
             const float x0 = (zz[e] - s1_t * eps) / sa_t;
-            float zn = sa_p * x0 + s1_p * eps;
+            float zn = sa_p * x0 + s1_p * eps + vn[e];
             if (p.mask) {
                 const float proper = sa_n * zi[e] + s1_n * nz[e];
                 zn = (1.f - mk) * proper + mk * zn;
@@ -177,6 +181,7 @@ inline unsigned grid_for(long work_items) {
 int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s) {
     if (p.B <= 0 || p.HW <= 0) return imd_set_error("ddim_cfg_step: empty latent");
     if (p.mask && (!p.z_img || !p.noise)) return imd_set_error("ddim_cfg_step: inpaint mask given without image latents / noise");
+    if (p.var_noise && p.coefs) return imd_set_error("ddim_cfg_step: the stochastic step (var_noise) takes host coefficients, not the device table");
     if (p.dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(ddim_cfg_step_kernel<true>, dim3(grid_for((long)p.B * p.HW)), dim3(256), 0, s, p);
     else if (p.dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(ddim_cfg_step_kernel<false>, dim3(grid_for((long)p.B * p.HW)), dim3(256), 0, s, p);
     else return imd_set_error("ddim_cfg_step: unknown dtype %d", p.dtype);

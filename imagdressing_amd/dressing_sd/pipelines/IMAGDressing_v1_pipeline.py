@@ -31,10 +31,11 @@ class IMAGDressing_v1(PipelineBase):
                  # --- extensions: bypass the out-of-scope encoders / inject latents / shard over ranks ---
                  ref_clip_hidden_states: Optional[torch.Tensor] = None, ref_image_latents: Optional[torch.Tensor] = None,
                  latents: Optional[torch.Tensor] = None, shard_over_ranks: bool = False, trace: Optional[list] = None, **kwargs):
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 (DDIM with noise) is not used by the reference scripts")
         if guidance_scale <= 1.0:
-            raise NotImplementedError("the reference always samples with classifier-free guidance (g=7.5)")
+            # the reference cannot run this either: its loop indexes the CFG pair unconditionally (cache["hidden_states"][1] :476-479,
+            # latent_model_input[1] :511) and null_prompt_embeds is only bound under do_classifier_free_guidance (:431-435)
+            raise NotImplementedError("guidance_scale <= 1: the reference's loop indexes the CFG pair unconditionally "
+                                      "(IMAGDressing_v1_pipeline.py:476-479, :511); sample with guidance_scale > 1")
         self.set_scale(image_scale)                                        # :374
         device = self.device
         self._cross_attention_kwargs = cross_attention_kwargs
@@ -52,5 +53,6 @@ class IMAGDressing_v1(PipelineBase):
         sa = self._sa_states(ref_lat, cloth_tokens, shard_over_ranks)                               # :465-480
         out = self.denoise(latents=lat, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
                            sa_hidden_states=sa, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                           callback=callback, callback_steps=callback_steps or 1, trace=trace)
+                           callback=callback, callback_steps=callback_steps or 1, trace=trace,
+                           eta=eta, generator=generator, variance_noise=kwargs.get("variance_noise"))           # eta: :451, :530
         return self._decode(out, output_type, generator)                                            # :544-547

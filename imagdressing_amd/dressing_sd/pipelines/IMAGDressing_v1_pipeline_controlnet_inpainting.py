@@ -43,8 +43,11 @@ class IMAGDressing_v1(PipelineBase):
                  ref_clip_hidden_states: Optional[torch.Tensor] = None, ref_image_latents: Optional[torch.Tensor] = None,
                  image_latents: Optional[torch.Tensor] = None, mask_latents: Optional[torch.Tensor] = None,
                  noise: Optional[torch.Tensor] = None, shard_over_ranks: bool = False, trace: Optional[list] = None, **kwargs):
-        if eta != 0.0 or guess_mode or guidance_scale <= 1.0 or strength != 1.0 or padding_mask_crop is not None or timesteps:
-            raise NotImplementedError("only the reference script's configuration (strength 1.0, eta 0, CFG on, no crop) is implemented")
+        if guess_mode or guidance_scale <= 1.0 or padding_mask_crop is not None or timesteps:
+            raise NotImplementedError("guess_mode, guidance_scale <= 1, padding_mask_crop and custom timesteps are not implemented "
+                                      "(the reference script uses none of them)")
+        if not 0.0 < float(strength) <= 1.0:
+            raise ValueError(f"The value of strength should in (0.0, 1.0] but is {strength}")           # diffusers check_inputs (0.0 leaves no step)
         callback = kwargs.pop("callback", None)
         callback_steps = kwargs.pop("callback_steps", None) or 1
         self.set_scale(image_scale)
@@ -57,19 +60,32 @@ class IMAGDressing_v1(PipelineBase):
             cloth_tokens, _ = self.encode_prompt(null_prompt, device, 1, False)
         else:
             cloth_tokens = self._cloth_tokens(ref_clip_image, ref_clip_hidden_states, device)
+        steps_run = min(int(num_inference_steps * float(strength)), num_inference_steps)          # the gate is over the timesteps actually run (:376-381)
         control = dict(image=to_image_tensor(control_image, device, normalize=False, size=(height, width), multiple=self.vae_scale_factor),
                        prompt_embeds=prompt_embeds,
                        negative_prompt_embeds=negative_prompt_embeds, scale=float(first(controlnet_conditioning_scale)),
-                       keep=controlnet_keep(num_inference_steps, float(first(control_guidance_start)), float(first(control_guidance_end))))
+                       keep=controlnet_keep(max(steps_run, 1), float(first(control_guidance_start)), float(first(control_guidance_end))))
         B = num_images_per_prompt
         h, w = height // self.vae_scale_factor, width // self.vae_scale_factor
-        # strength == 1.0: start from pure noise; the SAME noise re-noises the original latents in the blend (:496-498)
-        if noise is None:
-            noise = randn_tensor((B, 4, h, w), generator=generator, device=device, dtype=torch.float32)
-        lat = noise.to(device=device, dtype=torch.float32) if latents is None else latents.to(device=device, dtype=torch.float32)
-        lat = lat * self.scheduler.init_noise_sigma
-        if image_latents is None:
+        # strength == 1.0: start from pure noise; the SAME noise re-noises the original latents in the blend (:496-498).
+        # strength < 1.0 (:316-341 -> diffusers get_timesteps / prepare_latents): run the last int(steps * strength) timesteps,
+        # starting from add_noise(image_latents, noise, first of them).  Explicit ``latents`` are taken as the noise, as diffusers does.
+        if image_latents is None:                                             # (before the noise draw, like diffusers' prepare_latents)
             image_latents = self._image_latents(image, device, generator, size=(height, width))
+        if noise is None:
+            noise = latents if latents is not None else randn_tensor((B, 4, h, w), generator=generator, device=device, dtype=torch.float32)
+        init_steps = min(int(num_inference_steps * float(strength)), num_inference_steps)
+        t_start = max(num_inference_steps - init_steps, 0)
+        if init_steps < 1:
+            raise ValueError(f"After adjusting the num_inference_steps by strength parameter: {strength}, the number of pipeline "
+                             f"steps is {init_steps} which is < 1 and not appropriate for this pipeline.")
+        if latents is not None or float(strength) == 1.0:
+            lat = (noise if latents is None else latents).to(device=device, dtype=torch.float32) * self.scheduler.init_noise_sigma
+        else:
+            self.scheduler.set_timesteps(num_inference_steps, device=device)
+            t0 = int(self.scheduler.timesteps[t_start * getattr(self.scheduler, "order", 1)])
+            il = image_latents.to(device=device, dtype=torch.float32)
+            lat = self.scheduler.add_noise(il.expand(B, -1, -1, -1) if il.shape[0] != B else il, noise.to(device=device, dtype=torch.float32), t0)
         if mask_latents is None:                                              # prepare_mask_latents: nearest resize to h x w
             m = to_image_tensor(mask_image, device, normalize=False)[:, :1]
             m = (m >= 0.5).float()
@@ -80,5 +96,6 @@ class IMAGDressing_v1(PipelineBase):
         inpaint = dict(mask=mask_latents, image_latents=image_latents, noise=noise_s)
         out = self.denoise(latents=lat, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
                            sa_hidden_states=sa, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                           control=control, inpaint=inpaint, callback=callback, callback_steps=callback_steps, trace=trace)
+                           control=control, inpaint=inpaint, callback=callback, callback_steps=callback_steps, trace=trace,
+                           eta=eta, generator=generator, variance_noise=kwargs.get("variance_noise"), t_start=t_start)
         return self._decode(out, output_type, generator)

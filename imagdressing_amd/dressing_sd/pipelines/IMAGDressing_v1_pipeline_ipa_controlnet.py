@@ -82,8 +82,8 @@ class IMAGDressing_v1(PipelineBase):
                  ref_clip_hidden_states: Optional[torch.Tensor] = None, ref_image_latents: Optional[torch.Tensor] = None,
                  face_clip_hidden_states: Optional[torch.Tensor] = None, face_uncond_clip_hidden_states: Optional[torch.Tensor] = None,
                  latents: Optional[torch.Tensor] = None, shard_over_ranks: bool = False, trace: Optional[list] = None, **kwargs):
-        if eta != 0.0 or guess_mode or guidance_scale <= 1.0:
-            raise NotImplementedError("eta != 0, guess_mode and guidance_scale <= 1 are not used by the reference scripts")
+        if guess_mode or guidance_scale <= 1.0:
+            raise NotImplementedError("guess_mode and guidance_scale <= 1 are not used by the reference scripts (its loop indexes the CFG pair unconditionally)")
         has_face = face_clip_image is not None or face_clip_hidden_states is not None
         if not has_face:                                                      # :432-437
             self.set_scale(image_scale, lora_scale=0.0)
@@ -118,5 +118,6 @@ class IMAGDressing_v1(PipelineBase):
         sa = self._sa_states(ref_lat, cloth_tokens, shard_over_ranks)
         out = self.denoise(latents=lat, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds,
                            sa_hidden_states=sa, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
-                           control=control, callback=callback, callback_steps=callback_steps or 1, trace=trace)
+                           control=control, callback=callback, callback_steps=callback_steps or 1, trace=trace,
+                           eta=eta, generator=generator, variance_noise=kwargs.get("variance_noise"))
         return self._decode(out, output_type, generator)

@@ -166,8 +166,15 @@ class PipelineBase:
     def denoise(self, *, latents: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: torch.Tensor,
                 sa_hidden_states: Dict[str, torch.Tensor], num_inference_steps: int, guidance_scale: float,
                 control: Optional[dict] = None, inpaint: Optional[dict] = None,
-                callback: Optional[Callable] = None, callback_steps: int = 1, trace: Optional[list] = None) -> torch.Tensor:
+                callback: Optional[Callable] = None, callback_steps: int = 1, trace: Optional[list] = None,
+                eta: float = 0.0, generator=None, variance_noise: Optional[List[torch.Tensor]] = None, t_start: int = 0) -> torch.Tensor:
         """latents [B, 4, h, w] fp32 -> final latents [B, 4, h, w] fp32.
+
+        ``eta`` > 0 (DDIM only; other schedulers ignore it, like ``prepare_extra_step_kwargs``, IMAGDressing_v1_pipeline.py:102-119):
+        the stochastic step, noise per step = ``variance_noise[i]`` [B, 4, h, w] or a draw of that shape in the UNet's element type
+        from ``generator`` (what ``DDIMScheduler.step`` does with the reference's ``noise_pred``).
+        ``t_start``: skip the first t_start timesteps of the schedule (inpainting ``strength`` < 1,
+        ..._controlnet_inpainting.py:316-319 -> diffusers ``get_timesteps``); ``latents`` is then the noised image latent.
 
         ``control`` = dict(image=[1|B, 3, H, W] in [0,1] or NHWC8 bf16, prompt_embeds=[1,77,768],
         negative_prompt_embeds=[1,77,768], scale=float, keep=[float]*steps)
@@ -178,7 +185,9 @@ class PipelineBase:
         HW = h * w
         sch = self.scheduler
         sch.set_timesteps(num_inference_steps, device=dev)
-        timesteps = [int(t) for t in sch.timesteps]
+        timesteps = [int(t) for t in sch.timesteps][int(t_start) * getattr(sch, "order", 1):]
+        if not timesteps:
+            raise ValueError(f"no denoising steps left (num_inference_steps={num_inference_steps}, t_start={t_start})")
         z = latents.to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1).reshape(B, HW, Cl).contiguous()
         dt = self.unet.dtype
         x_in = torch.zeros(2 * B, h, w, 8, dtype=dt, device=dev)
@@ -205,6 +214,9 @@ class PipelineBase:
         if multistep and inp is not None:
             raise NotImplementedError("the inpainting blend is defined on the DDIM step (…inpainting.py:487-500)")
         keeps = None if control is None else [control.get("keep", [1.0] * len(timesteps))[i] for i in range(len(timesteps))]
+        stochastic = float(eta) > 0.0 and not multistep
+        if variance_noise is not None and stochastic and len(variance_noise) < len(timesteps):
+            raise ValueError(f"variance_noise has {len(variance_noise)} entries for {len(timesteps)} steps")
         ctrl_scale = 0.0 if control is None else float(control.get("scale", 1.0))
 
         def ddim_step(t, i=None, coefs=None):
@@ -222,10 +234,14 @@ class PipelineBase:
             else:
                 if inp is not None:
                     kw["a_next"] = sch.alpha(timesteps[i + 1]) if i < len(timesteps) - 1 else None
+                if stochastic:
+                    vn = variance_noise[i] if variance_noise is not None else randn_tensor((B, Cl, h, w), generator=generator, device=dev, dtype=dt)
+                    kw["var_noise"] = vn.to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1).reshape(B, HW, Cl).contiguous()
+                    kw["sigma"] = sch.sigma(timesteps[i], eta)
                 ops.ddim_cfg_step(z, eps, x_in.view(2 * B, HW, 8), guidance=float(guidance_scale), a_t=sch.alpha(timesteps[i]),
                                   a_prev=sch.alpha_prev(timesteps[i]), **kw)
 
-        use_graph = (getattr(self, "_step_graph", False) and not multistep and callback is None and trace is None
+        use_graph = (getattr(self, "_step_graph", False) and not multistep and not stochastic and callback is None and trace is None
                      and len(timesteps) > 2 and (keeps is None or len(set(keeps)) == 1) and ops.ATTN_EVENT_HOOK is None)
         if use_graph:
             # HIP-graph replay of the denoising step (opt-in, ``enable_step_graph``): step 0 runs eagerly on the pipeline's side stream

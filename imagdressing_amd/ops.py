@@ -592,9 +592,12 @@ def ddim_coefs(a_t, a_prev, a_next=None):
     return [a_t ** 0.5, (1 - a_t) ** 0.5, a_prev ** 0.5, (1 - a_prev) ** 0.5, an[0], an[1]]
 
 
-def ddim_cfg_step(z, eps, x_next, *, guidance, a_t=1.0, a_prev=1.0, mask=None, z_img=None, noise=None, a_next=None, coefs=None):
+def ddim_cfg_step(z, eps, x_next, *, guidance, a_t=1.0, a_prev=1.0, mask=None, z_img=None, noise=None, a_next=None, coefs=None,
+                  var_noise=None, sigma=0.0):
     """z [B,HW,4] fp32 (in place); eps [2B,HW,4] fp32; x_next [2B,HW,8] bf16 or None.  ``coefs``: device fp32 [6]
-    (:func:`ddim_coefs`) read by the kernel instead of a_t / a_prev / a_next (HIP-graph replay of a step)."""
+    (:func:`ddim_coefs`) read by the kernel instead of a_t / a_prev / a_next (HIP-graph replay of a step).
+    ``var_noise`` [B,HW,4] fp32 + ``sigma``: the stochastic DDIM step (eta > 0) -- diffusers' ``DDIMScheduler.step``:
+    direction coefficient sqrt(1 - a_prev - sigma^2), ``+ sigma * var_noise``."""
     ensure_device(z.device)
     B, HW = z.shape[0], z.shape[1]
     p = L.DdimParams()
@@ -605,6 +608,12 @@ def ddim_cfg_step(z, eps, x_next, *, guidance, a_t=1.0, a_prev=1.0, mask=None, z
     p.guidance = guidance
     p.sqrt_a_t, p.sqrt_1m_a_t = a_t ** 0.5, (1 - a_t) ** 0.5
     p.sqrt_a_prev, p.sqrt_1m_a_prev = a_prev ** 0.5, (1 - a_prev) ** 0.5
+    p.var_noise, p.sigma = None, 0.0
+    if var_noise is not None:
+        if var_noise.numel() != B * HW * 4:
+            raise L.ImdError(f"ddim_cfg_step: var_noise has {var_noise.numel()} elements, expected {B * HW * 4}")
+        p.var_noise, p.sigma = _dev(var_noise, torch.float32, "var_noise"), float(sigma)
+        p.sqrt_1m_a_prev = max(1 - a_prev - float(sigma) ** 2, 0.0) ** 0.5
     p.mask = _opt(mask, torch.float32, "mask")
     p.z_img = _opt(z_img, torch.float32, "z_img")
     p.noise = _opt(noise, torch.float32, "noise")

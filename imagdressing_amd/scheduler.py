@@ -53,14 +53,30 @@ class DDIMScheduler:
         prev = int(t) - self.num_train_timesteps // self.num_inference_steps
         return float(self.alphas_cumprod[prev]) if prev >= 0 else float(self.final_alpha_cumprod)
 
+    def sigma(self, t: int, eta: float) -> float:
+        """std_dev_t of diffusers' ``DDIMScheduler.step``: eta * sqrt(_get_variance(t, prev_t))."""
+        a_t, a_prev = self.alpha(t), self.alpha_prev(t)
+        return float(eta) * ((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)) ** 0.5
+
     # ---- diffusers-compatible tensor API (NCHW in / out), thin over the same kernel ----
-    def step(self, model_output, timestep, sample, eta: float = 0.0, return_dict: bool = False, **unused):
-        if eta != 0.0:
-            raise NotImplementedError("eta != 0 is not used by IMAGDressing")
+    def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output: bool = False, generator=None,
+             variance_noise=None, return_dict: bool = False, **unused):
+        """``eta`` > 0: the stochastic step; the noise is ``variance_noise`` or, like diffusers, a standard-normal draw of
+        ``model_output``'s shape and dtype from ``generator`` (the reference forwards both through ``prepare_extra_step_kwargs``,
+        IMAGDressing_v1_pipeline.py:102-119)."""
+        if use_clipped_model_output:
+            raise NotImplementedError("use_clipped_model_output (only meaningful with clip_sample=True, which the reference turns off)")
         B, Cc, H, W = sample.shape
         z = sample.float().permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous()
         e = model_output.float().permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous()
-        ops.ddim_cfg_step(z, torch.cat([e, e]), None, guidance=1.0, a_t=self.alpha(timestep), a_prev=self.alpha_prev(timestep))
+        kw = {}
+        if eta > 0:
+            if variance_noise is None:
+                from .dressing_sd.pipelines._base import randn_tensor
+                variance_noise = randn_tensor(tuple(model_output.shape), generator=generator, device=model_output.device, dtype=model_output.dtype)
+            kw = dict(var_noise=variance_noise.to(sample.device).float().permute(0, 2, 3, 1).reshape(B, H * W, Cc).contiguous(),
+                      sigma=self.sigma(timestep, eta))
+        ops.ddim_cfg_step(z, torch.cat([e, e]), None, guidance=1.0, a_t=self.alpha(timestep), a_prev=self.alpha_prev(timestep), **kw)
         out = z.view(B, H, W, Cc).permute(0, 3, 1, 2).to(sample.dtype)
         return (out,)
 

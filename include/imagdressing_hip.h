@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 5
+#define IMD_ABI_VERSION 6
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -160,6 +160,10 @@ typedef struct imd_ddim_params {
     const float* coefs;   /* NULL, or DEVICE pointer to 6 fp32 {sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev, sqrt_a_next,
                            * sqrt_1m_a_next} read by the kernel INSTEAD of the host scalars above: lets one captured HIP graph of a
                            * denoising step serve every timestep (the host refreshes 24 bytes per step, stream-ordered) */
+    const float* var_noise; /* NULL, or [B, HW, 4] fp32 standard-normal noise of the stochastic DDIM step (eta > 0, DDIMScheduler.step's
+                           * `variance_noise`): z_prev += sigma * var_noise BEFORE the inpaint blend; the caller then passes
+                           * sqrt_1m_a_prev = sqrt(1 - a_prev - sigma^2) (the direction coefficient of diffusers' step) */
+    float sigma;          /* eta * sqrt((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)); read only with var_noise */
 } imd_ddim_params;
 
 /* library / device */

@@ -36,14 +36,21 @@ class DDIMOracle:
     def scale_model_input(self, x, t=None):
         return x
 
-    def step(self, eps, t, x, eta=0.0):
+    def step(self, eps, t, x, eta=0.0, variance_noise=None):
+        """``DDIMScheduler.step`` (diffusers 0.24 scheduling_ddim.py: formula (12) of the DDIM paper).  eta > 0 adds
+        std_dev_t * variance_noise with std_dev_t = eta * sqrt((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)) and shrinks the
+        direction term to sqrt(1 - a_prev - std_dev_t^2) * eps; the noise is passed in (the library draws it from a generator)."""
         t = int(t)
         prev_t = t - self.T // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
-        assert eta == 0.0
-        return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+        std = eta * ((1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)) ** 0.5
+        prev = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps
+        if eta > 0:
+            assert variance_noise is not None
+            prev = prev + std * variance_noise
+        return prev
 
     def add_noise(self, x0, noise, t):
         a = self.alphas_cumprod[int(t)]

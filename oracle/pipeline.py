@@ -36,12 +36,22 @@ def denoise(
     ref_latents, num_inference_steps: int, guidance_scale: float,
     controlnet=None, control_image=None, prompt_embeds_control=None, conditioning_scale: float = 1.0,
     inpaint: Optional[dict] = None, trace: Optional[list] = None,
+    eta: float = 0.0, variance_noise: Optional[list] = None, strength: float = 1.0,
 ):
     """Returns the final latents [1,4,h,w].  ``inpaint`` = dict(mask [1,1,h,w], image_latents,
     noise) enables the per-step blend (..._controlnet_inpainting.py:487-500).
     ``prompt_embeds_control`` = cat([negative, prompt]) *text-only* embeds [2,77,768]
-    (..._ipa_controlnet.py:550).  ``trace`` collects latents after every step."""
+    (..._ipa_controlnet.py:550).  ``trace`` collects latents after every step.
+    ``eta`` > 0 with ``variance_noise`` = one [1,4,h,w] tensor per executed step: the stochastic DDIM step the reference reaches
+    through ``prepare_extra_step_kwargs`` (IMAGDressing_v1_pipeline.py:102-119, :530).  ``strength`` < 1 (inpainting only,
+    ..._controlnet_inpainting.py:316-341, diffusers' ``get_timesteps`` / ``prepare_latents``): the last
+    int(steps * strength) timesteps are run, starting from add_noise(image_latents, noise, first of them)."""
     timesteps = scheduler.set_timesteps(num_inference_steps)
+    if strength < 1.0:
+        assert inpaint is not None
+        init = min(int(num_inference_steps * strength), num_inference_steps)
+        timesteps = timesteps[max(num_inference_steps - init, 0):]
+        latents = scheduler.add_noise(inpaint["image_latents"], inpaint["noise"], timesteps[0])
     sa = None
     for i, t in enumerate(timesteps):
         if i == 0:
@@ -57,7 +67,7 @@ def denoise(
         eps_c = unet(lmi[0:1], t, prompt_embeds, cross_attention_kwargs={"sa_hidden_states": sa}, **kw_c)
         eps_u = unet(lmi[1:2], t, negative_prompt_embeds, **kw_u)               # no garment branch
         eps = eps_u + guidance_scale * (eps_c - eps_u)                            # :521-527
-        latents = scheduler.step(eps, t, latents)                                 # :530-532
+        latents = scheduler.step(eps, t, latents, **({} if eta == 0 else dict(eta=eta, variance_noise=variance_noise[i])))   # :530-532
         if inpaint is not None:
             proper = inpaint["image_latents"]
             if i < len(timesteps) - 1:

@@ -295,6 +295,83 @@ def test_pipeline_inpaint_small(dtype):
 
 
 @torch.no_grad()
+def test_pipeline_small_stochastic_ddim(small_pair):
+    """eta = 0.6 through the pipeline call (eta -> prepare_extra_step_kwargs -> DDIMScheduler.step, IMAGDressing_v1_pipeline.py:451,:530)
+    with the per-step noise passed in == the oracle loop with the same noise; and a generator-driven run is reproducible."""
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+    from oracle.ddim import DDIMOracle
+    from oracle.pipeline import denoise
+    p = small_pair
+    steps, gs, eta = 10, 7.5, 0.6
+    lat = g(42, 1, 4, 16, 16)
+    pe, ne = g(10, 1, 77, 64, scale=0.5), g(11, 1, 77, 64, scale=0.5)
+    cloth = g(12, 2, 16, 64, scale=0.5); refl = g(13, 1, 4, 16, 16)
+    vn = [g(100 + i, 1, 4, 16, 16) for i in range(steps)]
+    ref = denoise(p["o_unet"], p["o_ref"], DDIMOracle(), lat, pe, ne, cloth, refl, steps, gs, eta=eta, variance_noise=vn)
+    ref0 = denoise(p["o_unet"], p["o_ref"], DDIMOracle(), lat, pe, ne, cloth, refl, steps, gs)
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           image_encoder=None, ImgProj=lambda h: h, scheduler=_sched())
+    kw = dict(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=128, height=128, num_inference_steps=steps,
+              guidance_scale=gs, prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(),
+              ref_image_latents=refl.cuda(), latents=lat.cuda(), output_type="latent")
+    out = pipe(eta=eta, variance_noise=[v.cuda() for v in vn], **kw).images
+    st = err_stats(out, ref); record(f"pipeline_small_stochastic_ddim[{p['dtype']}]", st)
+    bar = _traj_bar(p["dtype"])
+    assert torch.isfinite(out).all()
+    assert st["max_abs"] < bar["max_abs"] * max(st["ref_std"], 1.0) and st["rel_rms"] < bar["rel_rms"], st
+    assert err_stats(out, ref0)["rel_rms"] > 10 * st["rel_rms"]            # it is not the deterministic trajectory
+    a = pipe(eta=eta, generator=torch.Generator("cuda").manual_seed(5), **kw).images
+    b = pipe(eta=eta, generator=torch.Generator("cuda").manual_seed(5), **kw).images
+    c = pipe(eta=eta, generator=torch.Generator("cuda").manual_seed(6), **kw).images
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    with pytest.raises(NotImplementedError):
+        pipe(**dict(kw, guidance_scale=1.0))                               # the reference's loop cannot run without the CFG pair either
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_pipeline_inpaint_small_strength(dtype):
+    """strength = 0.6 (..._controlnet_inpainting.py:316-341 -> diffusers get_timesteps / prepare_latents): the last int(10 * 0.6) = 6
+    timesteps, from the image latents noised to the first of them; ControlNet gate over the 6 steps that run."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline_controlnet_inpainting import IMAGDressing_v1
+    from oracle.ddim import DDIMOracle
+    from oracle.pipeline import denoise
+    p = build_pair(SMALL, seed=5, with_controlnet=True, dtype=dtype)
+    steps, gs, strength = 10, 5.0, 0.6
+    noise = g(42, 1, 4, 16, 24)
+    pe, ne = g(10, 1, 77, 64, scale=0.5), g(11, 1, 77, 64, scale=0.5)
+    cloth = g(12, 2, 16, 64, scale=0.5); refl = g(13, 1, 4, 16, 16)
+    img_lat = g(17, 1, 4, 16, 24)
+    mask = torch.zeros(1, 1, 16, 24); mask[:, :, 4:12, 6:18] = 1.0
+    ctrl = torch.rand(1, 3, 128, 192, generator=torch.Generator().manual_seed(18))
+    tr = []
+    ref = denoise(p["o_unet"], p["o_ref"], DDIMOracle(), None, pe, ne, cloth, refl, steps, gs, controlnet=p["o_ctrl"],
+                  control_image=ctrl, prompt_embeds_control=torch.cat([ne, pe]), conditioning_scale=1.0,
+                  inpaint=dict(mask=mask, image_latents=img_lat, noise=noise), strength=strength, trace=tr)
+    assert len(tr) == 6
+    pipe = IMAGDressing_v1(vae=None, reference_unet=p["e_ref"], unet=p["e_unet"], tokenizer=None, text_encoder=None,
+                           controlnet=p["e_ctrl"], image_encoder=None, ImgProj=lambda h: h, scheduler=_sched())
+    kw = dict(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=192, height=128,
+              num_inference_steps=steps, guidance_scale=gs, control_image=ctrl.cuda(), prompt_embeds=pe.cuda(),
+              negative_prompt_embeds=ne.cuda(), ref_clip_hidden_states=cloth[1:2].cuda(), ref_image_latents=refl.cuda(),
+              image_latents=img_lat.cuda(), mask_latents=mask.cuda(), noise=noise.cuda(), output_type="latent")
+    mine = []
+    out = pipe(strength=strength, trace=mine, **kw).images
+    assert len(mine) == 6
+    st = err_stats(out, ref); record(f"pipeline_inpaint_small_strength[{dtype}]", st)
+    bar = _traj_bar(dtype)
+    assert torch.isfinite(out).all()
+    assert st["max_abs"] < bar["max_abs"] * max(st["ref_std"], 1.0) and st["rel_rms"] < bar["rel_rms"], st
+    keep = (mask == 0).expand(1, 4, -1, -1)
+    assert torch.allclose(out.cpu()[keep], img_lat[keep], atol=1e-5)
+    for bad in (0.0, 1.5, 0.05):                       # diffusers: strength outside (0, 1]; fewer than one step left
+        with pytest.raises(ValueError):
+            pipe(strength=bad, **kw)
+
+
+@torch.no_grad()
 def test_build_engines_from_imagdressing_checkpoint(tmp_path):
     """imagdressing_amd.checkpoint.build_engines (the reference's prepare(), inference_IMAGdressing.py:40-135) from a
     DeepSpeed-style checkpoint FILE == engines built directly from the same tensors: bit-identical UNet outputs."""

@@ -35,6 +35,31 @@ def test_ddim_schedule_matches_oracle_and_known_values(n):
     assert float(o.alphas_cumprod[999]) == pytest.approx(0.004660, abs=2e-5)
 
 
+def test_stochastic_ddim_step_of_the_oracle_and_the_host_sigma():
+    """eta > 0: the oracle's step is formula (12)/(16) of the DDIM paper as diffusers 0.24 writes it; the host-side sigma handed
+    to the fused kernel is the same number; eta = 1 at the 1000-step schedule is the DDPM posterior variance"""
+    s, o = make_sched(), DDIMOracle()
+    s.set_timesteps(50); ts = o.set_timesteps(50)
+    x = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(0)); e = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(1))
+    n = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(2))
+    for t in (int(ts[0]), int(ts[20]), int(ts[-1])):
+        a_t, a_p = s.alpha(t), s.alpha_prev(t)
+        for eta in (0.25, 1.0):
+            std = eta * ((1 - a_p) / (1 - a_t) * (1 - a_t / a_p)) ** 0.5
+            assert s.sigma(t, eta) == pytest.approx(std, rel=1e-12)
+            det, sto = o.step(e, t, x), o.step(e, t, x, eta=eta, variance_noise=n)
+            # stochastic = deterministic with the direction coefficient shrunk, plus std * noise
+            exp = det - ((1 - a_p) ** 0.5 - (1 - a_p - std ** 2) ** 0.5) * e + std * n
+            assert torch.allclose(sto, exp, atol=1e-6)
+        assert torch.equal(o.step(e, t, x, eta=0.0), o.step(e, t, x))
+    # eta = 1 on consecutive timesteps: sigma^2 = beta_tilde_t = (1 - a_{t-1}) / (1 - a_t) * beta_t (DDPM posterior variance)
+    s.set_timesteps(1000)
+    t = 500
+    beta_t = 1 - s.alpha(t) / s.alpha(t - 1)
+    assert s.alpha_prev(t) == s.alpha(t - 1)
+    assert s.sigma(t, 1.0) ** 2 == pytest.approx((1 - s.alpha(t - 1)) / (1 - s.alpha(t)) * beta_t, rel=1e-9)
+
+
 def test_unet_and_controlnet_inventories_match_oracle_modules():
     u = sd15.UNet2DConditionModel().state_dict()
     s = E.unet_param_shapes()

@@ -744,6 +744,46 @@ def test_ddim_cfg_step(ops, inpaint, dt):
     assert float(xn[..., 4:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("inpaint", [False, True])
+@pytest.mark.parametrize("eta", [0.3, 1.0])
+def test_ddim_cfg_step_stochastic(ops, inpaint, eta):
+    """eta > 0 (DDIMScheduler.step's variance noise, reached through prepare_extra_step_kwargs, IMAGDressing_v1_pipeline.py:102-119):
+    the fused step == oracle step with the same noise; the noise is added BEFORE the inpaint blend"""
+    from oracle.ddim import DDIMOracle
+    from imagdressing_amd.scheduler import DDIMScheduler
+    B, HW = 2, 700
+    sch = DDIMOracle(); sch.set_timesteps(50)
+    mine = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                         set_alpha_to_one=False, steps_offset=1); mine.set_timesteps(50)
+    for k in (0, 7, 49):                          # first, middle, last (prev_t < 0 -> final_alpha_cumprod) step
+        t = int(sch.timesteps[k])
+        z = rnd(1, B, HW, 4); eps = rnd(2, 2 * B, HW, 4); vn = rnd(6, B, HW, 4); g = 7.5
+        e = eps[B:] + g * (eps[:B] - eps[B:])
+        ref = sch.step(e, t, z, eta=eta, variance_noise=vn)
+        assert not torch.allclose(ref, sch.step(e, t, z), atol=1e-3)
+        kw = {}
+        if inpaint:
+            mask = (rnd(3, B, HW) > 0).float(); zi = rnd(4, B, HW, 4); nz = rnd(5, B, HW, 4)
+            proper = zi if k == 49 else sch.add_noise(zi, nz, int(sch.timesteps[k + 1]))
+            ref = (1 - mask[..., None]) * proper + mask[..., None] * ref
+            kw = dict(mask=dev(mask), z_img=dev(zi), noise=dev(nz), a_next=None if k == 49 else float(sch.alphas_cumprod[int(sch.timesteps[k + 1])]))
+        zd = dev(z.clone()); xn = torch.empty(2 * B, HW, 8, dtype=bf16, device="cuda")
+        ops.ddim_cfg_step(zd, dev(eps), xn, guidance=g, a_t=mine.alpha(t), a_prev=mine.alpha_prev(t), var_noise=dev(vn), sigma=mine.sigma(t, eta), **kw)
+        assert_close(zd, ref, atol=2e-4, rtol=1e-4, what=f"stochastic ddim z (step {k})")
+        assert_close(xn[:B, :, :4], ref, atol=3e-2, what="next input")
+    # the tensor API of the scheduler (NCHW), noise passed in and drawn from a generator
+    x = rnd(7, 2, 4, 16, 24); mo = rnd(8, 2, 4, 16, 24); vn = rnd(9, 2, 4, 16, 24)
+    t = int(sch.timesteps[20])
+    got = mine.step(dev(mo), t, dev(x), eta=eta, variance_noise=dev(vn))[0]
+    assert_close(got, sch.step(mo, t, x, eta=eta, variance_noise=vn), atol=2e-4, rtol=1e-4, what="scheduler.step(eta)")
+    g1 = mine.step(dev(mo), t, dev(x), eta=eta, generator=torch.Generator("cuda").manual_seed(3))[0]
+    g2 = mine.step(dev(mo), t, dev(x), eta=eta, generator=torch.Generator("cuda").manual_seed(3))[0]
+    g3 = mine.step(dev(mo), t, dev(x), eta=eta, generator=torch.Generator("cuda").manual_seed(4))[0]
+    assert torch.equal(g1, g2) and not torch.equal(g1, g3)
+    with pytest.raises(ops.L.ImdError):
+        ops.ddim_cfg_step(dev(rnd(1, B, HW, 4)), dev(eps), None, guidance=g, var_noise=dev(rnd(6, B, HW + 1, 4)), sigma=0.1)
+
+
 @DTS
 def test_add_concat_cast(ops, dt):
     a = rnd(1, 2, 50, 320).to(dt); b = rnd(2, 2, 50, 640).to(dt); c = rnd(3, 2, 50, 640).to(dt)
