@@ -43,7 +43,11 @@ class IMAGDressing_v1(PipelineBase):
                  ref_clip_hidden_states: Optional[torch.Tensor] = None, ref_image_latents: Optional[torch.Tensor] = None,
                  latents: Optional[torch.Tensor] = None, shard_over_ranks: bool = False, trace: Optional[list] = None, **kwargs):
         if guess_mode or guidance_scale <= 1.0:
-            raise NotImplementedError("guess_mode and guidance_scale <= 1 are not used by the reference scripts (its loop indexes the CFG pair unconditionally)")
+            # neither runs in the reference: with guess_mode its ControlNet sees the cond half only and the loop then indexes
+            # down_block[1] of a batch-1 tensor (..._ipa_controlnet.py:634-639, :662-665; the zero-padding lines are commented out);
+            # without CFG latent_model_input[1] does not exist (:672, :690)
+            raise NotImplementedError("guess_mode / guidance_scale <= 1: the reference's loop indexes the CFG pair of the ControlNet "
+                                      "residuals and of the latents unconditionally (..._ipa_controlnet.py:662-690)")
         self.set_scale(image_scale)
         device = self.device
         self._cross_attention_kwargs = cross_attention_kwargs
