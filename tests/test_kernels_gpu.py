@@ -369,7 +369,7 @@ def test_conv3x3(ops, cfg, B, H, W, Cin, Cout, stride, ups, dt):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,split", [
     (2, 16, 16, 64, 64, 1), (1, 8, 32, 32, 320, 1), (3, 24, 16, 96, 132, 1), (1, 32, 32, 320, 320, 1), (2, 16, 16, 640, 256, 4),
-    (1, 8, 16, 1280, 128, 8),
+    (1, 8, 16, 1280, 128, 8), (2, 16, 16, 640, 320, 2), (1, 16, 32, 64, 192, 1),      # (N = 320 / 192: a narrow last channel tile, 4 x 1 waves)
     # ragged maps: tiles hang over the right / bottom edge (the 96 x 72 latent of BASELINE configs[4] and its 48 x 36 level)
     (1, 96, 72, 320, 320, 1), (2, 48, 36, 640, 640, 2), (1, 12, 18, 64, 64, 1), (2, 9, 17, 32, 40, 1)])
 @pytest.mark.parametrize("reg_staged", [False, True], ids=["dma", "regs"])
