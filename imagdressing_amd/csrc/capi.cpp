@@ -117,6 +117,7 @@ int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* co
 }
 
 int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (p && imd_conv_patch_supported(*p)) ? 1 : 0; }
+int imd_conv_patch2_supported(const imd_conv_gemm_params* p) { return (p && imd_conv_patch2_supported(*p)) ? 1 : 0; }
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return p ? imd_conv_patch_stats_parts_of(*p) : 0; }
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return (p && imd_gemm_dma_supported(*p)) ? 1 : 0; }
 

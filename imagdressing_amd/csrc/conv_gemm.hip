@@ -358,7 +358,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 4: case 5: case 8: *bm = 128; *bn = 128; return 0;
         case 3: case 7: *bm = 64; *bn = 64; return 0;
         case 6: *bm = 64; *bn = 320; return 0;
-        case 9: *bm = 256; *bn = 128; return 0;
+        case 9: case 21: *bm = 256; *bn = 128; return 0;
         case 10: case 16: *bm = 256; *bn = 256; return 0;
         case 17: case 18: case 19: case 20: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
@@ -472,6 +472,17 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             if (h) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
             else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
             return imd_check_launch("conv_patch split-K finish");
+        }
+        case 21: {  // halo patch, 16 x 16 pixel tiles (conv_patch2.hip)
+            p.splitk_counters = nullptr;
+            int rc = imd_launch_conv_patch2(p, s);
+            if (rc || p.split_k <= 1) return rc;
+            const long chunks = (long)p.M * ((p.N + 7) / 8);
+            long blocks = (chunks + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            if (h) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+            return imd_check_launch("conv_patch2 split-K finish");
         }
         case 12: return imd_launch_row_linear(p, 0, 0.f, s);      // row-resident kernel (row_linear.hip): K = 320, N <= 320
         case 13: return imd_launch_row_linear_k640(p, 0, 0.f, s); // row-resident split-K kernel (row_linear_k640.hip): K = 640, N % 160 == 0

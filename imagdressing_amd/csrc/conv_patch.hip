@@ -90,7 +90,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     const int split = blockIdx.y;
     const int per = (nchunks + p.split_k - 1) / p.split_k;
     const int c_begin = split * per;
+#ifdef PATCH_T_NOLOOP
+    const int c_end = c_begin;                  // timing probe: launch + prologue + epilogue only
+#else
     const int c_end = min(nchunks, c_begin + per);
+#endif
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, p.w_bytes, 0x00020000);
