@@ -17,6 +17,8 @@ for name, (B, H, W, Cin, Cout) in {"L0 320->320": (8, 64, 64, 320, 320), "L0 640
     xs = [torch.randn(B, H, W, Cin, device="cuda").to(dt) for _ in range(4)]
     ws = [(torch.randn(Cout, 9 * Cin, device="cuda") * (9 * Cin) ** -0.5).to(dt) for _ in range(4)]
     bias = torch.randn(Cout, device="cuda")
+    if os.environ.get("PATCH_PROBE_ZERO"):            # zero operands: same instruction stream, no data toggling (power probe)
+        for t in xs + ws: t.zero_()
     for cfg in CFGS:
       for sk in SPLITS:
         i = [0]
