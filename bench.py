@@ -371,6 +371,9 @@ def main():
             return None
         avg_s = sum(att_ms) / len(att_ms) * 1e-3
         fl = attn_flops_hybrid_level0(batch, r["N0"], r["N0"], 320)
+        fused_proj = bool(ops.FUSED_OUT_PROJ and ops.attention_proj_supported(8, r["N0"], 40))
+        if fused_proj:                 # the launch also carries to_out[0] + bias + residual of the block (ABI v7): 2 B N C^2
+            fl += 2.0 * (2 * batch) * r["N0"] * 320 * 320
         ach = fl / avg_s / 1e12
         traffic = tsrc = None
         if measure_traffic:
@@ -385,7 +388,7 @@ def main():
                         traffic = json.load(f).get("traffic_bytes")
                     tsrc = "/".join(rel) + " (rocprofv3 --pmc passes of this kernel and shape; not re-measured in this run)"
                     break
-        return dict(bound="mfma", kernel="fused hybrid attention (d = 40), UNet level 0, CFG batch",
+        return dict(bound="mfma", kernel="fused hybrid attention (d = 40), UNet level 0, CFG batch" + (" + out-projection + residual in the same launch" if fused_proj else ""),
                     achieved=round(ach, 2), peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4),
                     traffic=traffic, traffic_source=tsrc, launches=len(att_ms), avg_launch_ms=round(avg_s * 1e3, 4),
                     flops_per_launch=fl, algorithmic_bytes_per_launch=attn_bytes_hybrid_level0(batch, r["N0"], r["N0"]))

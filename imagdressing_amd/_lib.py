@@ -51,6 +51,8 @@ class AttnParams(C.Structure):
         ("L1", C.c_int), ("L1P", C.c_int), ("kv1_bdiv", C.c_int),
         ("L2", C.c_int), ("L2P", C.c_int), ("kv2_bdiv", C.c_int),
         ("out_ld", C.c_int), ("dtype", C.c_int), ("flags", C.c_int), ("causal", C.c_int), ("k_pad_one", C.c_int),
+        ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("proj_res", C.c_void_p), ("proj_out", C.c_void_p),
+        ("proj_res_ld", C.c_int), ("proj_out_ld", C.c_int), ("proj_counters", C.c_void_p),
     ]
 
 
@@ -135,8 +137,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if lib.imd_abi_version() != 6:
-            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 6")
+        if lib.imd_abi_version() != 7:
+            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 7")
         _lib = lib
     return _lib
 

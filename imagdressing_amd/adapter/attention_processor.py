@@ -266,6 +266,11 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
     if kv2 is not None and scale2 is not None:
         kw = dict(k2=kv2[0], v2t=kv2[1], L2=kv2[2], L2P=kv2[3], kv2_bdiv=kv2_bdiv, scale2=scale2)
     # every K operand on this path comes from ops.k_buffer (pad column = 1): the d = 40 kernel may stage by LDS-DMA
+    if ops.FUSED_OUT_PROJ and ops.attention_proj_supported(heads, N, D):
+        # the 64x64-level blocks: to_out[0] + bias + residual ride in the attention launch (ABI v7) -- the hybrid block is TWO launches
+        out = torch.empty(B, N, Cc, dtype=dt, device=dev)
+        return ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True,
+                             proj=(wo, bo, residual, out), **kw)
     ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True, **kw)
     res2 = None if residual is None else residual.view(B * N, Cc)
     return ops.linear(o.view(B * N, Cc), wo, bo, res=res2).view(B, N, Cc)

@@ -471,6 +471,18 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("attention: unknown dtype %d", p.dtype);
     if (p.causal && (p.k2 != nullptr || p.L1 != p.N)) return imd_set_error("attention: the causal mask needs a single key set with L1 == N");
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if (p.proj_w != nullptr) {          // fused out-projection: the d = 40 kernel (variant 10) only
+        if (p.D != 40 || p.H * p.D != 320 || p.N < 512 || p.causal)
+            return imd_set_error("attention: the fused out-projection needs head dim 40, 8 heads, N >= 512, no causal mask (got D=%d H=%d N=%d)", p.D, p.H, p.N);
+        if (!p.proj_out || !p.proj_counters) return imd_set_error("attention: fused out-projection without proj_out / proj_counters");
+        if ((p.out_ld % 8) || (p.proj_out_ld % 8) || (p.proj_res && (p.proj_res_ld % 8)))
+            return imd_set_error("attention: fused out-projection needs out_ld, proj_out_ld and proj_res_ld %% 8 == 0");
+        if ((reinterpret_cast<uintptr_t>(p.out) | reinterpret_cast<uintptr_t>(p.proj_w) | reinterpret_cast<uintptr_t>(p.proj_out) |
+             reinterpret_cast<uintptr_t>(p.proj_res) | reinterpret_cast<uintptr_t>(p.proj_b)) & 15)
+            return imd_set_error("attention: fused out-projection needs 16-byte aligned out / proj_w / proj_out / proj_res / proj_b");
+        if ((size_t)p.B * p.N * p.out_ld * 2 >= 0x80000000ull) return imd_set_error("attention: fused out-projection: out buffer beyond 2 GiB");
+        return imd_launch_attention_d40(p, 10, s);
+    }
     switch (p.D) {
         case 40:
             if (g_attn_qw40 >= 6 && p.N >= 512 && !p.causal) return imd_launch_attention_d40(p, g_attn_qw40, s);

@@ -67,6 +67,138 @@ __device__ __forceinline__ uint32_t pk_max3(uint32_t a, uint32_t b, uint32_t c) 
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_maximum(__builtin_elementwise_maximum(x, y), z));
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// PROJ (VAR & 1048576, round 3): the block's out-projection (to_out[0] + bias + residual, attention_processor.py:614-617) inside the
+// attention launch -- the level-0 hybrid block becomes two launches (norm1 + q/k/v projection, this one).  The projection needs
+// all 8 heads of a row, a workgroup owns one head of 256 rows, and the heads of a row block run on different XCDs (private,
+// non-coherent L2s), so the heads are joined the way gemm_common.h joins K slices: every workgroup stores its O tile WRITE-THROUGH
+// (sc0 sc1), waits for the acknowledgements, then takes a ticket from a device-scope counter of its (batch, row block); the
+// workgroup that draws the last ticket reads the 256 x 320 O tile back from the memory side (sc0 sc1 loads, never a stale L1 / L2
+// line), multiplies it with W_o out of LDS and writes  residual + bias + O W_o^T.  Nobody waits for anybody (no deadlock, no spin);
+// the counter is left at zero.  Result: identical up to fp32 summation order to imd_conv_gemm on the same O.
+// ------------------------------------------------------------------------------------------------------------------------------
+constexpr int AUX_WT = 17;                  // buffer cache policy bits sc0 (1) | sc1 (16): write-through stores / memory-side loads
+typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
+constexpr int PJ_C = 320, PJ_KC = 32, PJ_ROWS = 128, PJ_NH = 160;
+constexpr int PJ_LDS = 64 * (PJ_NH + 4) * 4;               // the epilogue tile (64 rows x 164 fp32 = 41 KB) > 8 KB of O rows + 10 KB of W_o rows per chunk
+
+template <bool F16>
+__device__ __forceinline__ void attn_out_proj(const AttnParams& p, int b, int row0, int nrows, char* smem) {
+    using E = El<F16>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, col = lane & 31;
+    char* As = smem;                                            // [128 O rows][64 B]
+    char* Ws = smem + PJ_ROWS * 64;                             // [160 W_o rows][64 B]
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.proj_w), 0, PJ_C * PJ_C * 2, 0x00020000);
+    // unpadded 64-byte LDS rows, piece c of row r at c ^ ((r >> 2) & 3) (gemm_dma.hip's map: conflict-free ds_read_b128).
+    // A pass = 128 rows x 160 channels (wave w: rows 32 w .. 32 w + 31, five 32-channel blocks = 80 accumulator registers); a chunk =
+    // 32 of the 320 input channels: 128 x 4 O pieces (two per thread) + 160 x 4 W_o pieces (two or three per thread)
+    int a_dst[2], w_dst[3];
+    uint32_t w_src0[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = tid + 256 * i, row = s >> 2, pc = s & 3;
+        a_dst[i] = row * 64 + ((pc ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int s = tid + 256 * i, row = s >> 2, pc = s & 3;
+        w_dst[i] = row * 64 + ((pc ^ ((row >> 2) & 3)) << 4);
+        w_src0[i] = s < PJ_NH * 4 ? (uint32_t)((row * PJ_C + pc * 8) * 2) : OOB;
+    }
+    const int frow = 32 * wave + col;                           // this lane's O row inside the 128-row pass
+    const int a_fr = frow * 64, a_sw = (frow >> 2) & 3;
+    constexpr int NCH = PJ_C / PJ_KC, PF = 3;                   // 10 chunks; operands fetched THREE chunks ahead (O comes from the memory side)
+    for (int ps = 0; ps * PJ_ROWS < 2 * nrows; ++ps) {          // passes: (row half, channel half)
+        const int r_base = row0 + (ps >> 1) * PJ_ROWS, nh = (ps & 1) * PJ_NH;
+        if (r_base - row0 >= nrows) break;
+        uint32_t a_src[2], w_src[3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = tid + 256 * i, row = s >> 2, pc = s & 3;
+            a_src[i] = (r_base + row < p.N) ? (uint32_t)((((size_t)b * p.N + r_base + row) * p.out_ld + pc * 8) * 2) : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w_src[i] = w_src0[i] == OOB ? OOB : w_src0[i] + (uint32_t)(nh * PJ_C * 2);
+        f32x16 acc[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        v4u a_r[PF][2], w_r[PF][3];
+        auto fetch = [&](int ch, v4u (&ad)[2], v4u (&wd)[3]) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ad[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, (int)(a_src[i] == OOB ? OOB : a_src[i] + ch * PJ_KC * 2), 0, AUX_WT);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(w_src[i] == OOB ? OOB : w_src[i] + ch * PJ_KC * 2), 0, 0);
+        };
+#pragma unroll
+        for (int c = 0; c < PF; ++c) fetch(c, a_r[c], w_r[c]);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            __syncthreads();                                    // the previous chunk's fragment reads are done
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<v4u*>(As + a_dst[i]) = a_r[ch % PF][i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (i < 2 || tid < PJ_NH * 4 - 512) *reinterpret_cast<v4u*>(Ws + w_dst[i]) = w_r[ch % PF][i];
+            if (ch + PF < NCH) fetch(ch + PF, a_r[ch % PF], w_r[ch % PF]);     // issued BEFORE the matrix work of this chunk
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < PJ_KC / 16; ++kk) {
+                const uint4 xf = *reinterpret_cast<const uint4*>(As + a_fr + (((2 * kk + hi) ^ a_sw) << 4));
+                uint4 wf[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int wr = 32 * j + col;
+                    wf[j] = *reinterpret_cast<const uint4*>(Ws + wr * 64 + (((2 * kk + hi) ^ ((wr >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[j] = E::mfma(wf[j], xf, acc[j]);
+            }
+        }
+        // epilogue through LDS, 64 rows at a time (the accumulators hold one row per lane: stored directly that is 8-byte pieces at a
+        // 640-byte stride, store-issue-bound; from LDS every thread moves 16 contiguous bytes of a row): residual + bias + O W_o^T
+        float* Cs = reinterpret_cast<float*>(smem);
+        constexpr int CLDP = PJ_NH + 4, CPRP = PJ_NH / 8;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                                    // fragment reads / the previous half's reads are done
+            if ((wave >> 1) == half) {
+                const int row_l = 32 * (wave & 1) + col;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(Cs + row_l * CLDP + 32 * j + 8 * q + 4 * hi) =
+                            make_float4(acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]);
+            }
+            __syncthreads();
+            for (int c = tid; c < 64 * CPRP; c += 256) {
+                const int row_l = c / CPRP, cc = (c - row_l * CPRP) * 8;
+                const int r = r_base + half * 64 + row_l;
+                if (r >= p.N) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(Cs + row_l * CLDP + cc);
+                const float4 v1 = *reinterpret_cast<const float4*>(Cs + row_l * CLDP + cc + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                const int c0 = nh + cc;
+                if (p.proj_b) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(p.proj_b + c0), b1 = *reinterpret_cast<const float4*>(p.proj_b + c0 + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (p.proj_res) {
+                    const uint4 rr = *reinterpret_cast<const uint4*>(p.proj_res + ((size_t)b * p.N + r) * p.proj_res_ld + c0);
+                    v[0] += E::lo(rr.x); v[1] += E::hi(rr.x); v[2] += E::lo(rr.y); v[3] += E::hi(rr.y);
+                    v[4] += E::lo(rr.z); v[5] += E::hi(rr.z); v[6] += E::lo(rr.w); v[7] += E::hi(rr.w);
+                }
+                *reinterpret_cast<uint4*>(p.proj_out + ((size_t)b * p.N + r) * p.proj_out_ld + c0) =
+                    make_uint4(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]), E::pack2(v[4], v[5]), E::pack2(v[6], v[7]));
+            }
+        }
+    }
+}
+
 // VAR bit 0: MFMA / VALU interleave written out and pinned   bit 1: plain (not XCD-aware) work order
 //   8192 (TAIL): head-dim rows 32..40 of O^T += V^T P^T (+ the all-ones row 40 that yields the softmax denominator) on
 //   v_mfma_f32_16x16x32 instead of a second 32x32x16 row block: 16 padded rows instead of 32, i.e. 6 instead of 7
@@ -87,6 +219,8 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
     using E = El<F16>;
     constexpr bool DMA = (VAR & 128) != 0;
     constexpr bool TAIL = (VAR & 8192) != 0;
+    constexpr bool PROJ = (VAR & 1048576) != 0;            // out-projection fused: O tiles stored write-through, last head of a row block projects
+    static_assert(!PROJ || (TAIL && !(VAR & 32768)), "the fused out-projection lives in the 4-wave kernel with the 16x16x32 tail");
     constexpr int NW = (VAR & 32768) ? 8 : 4;              // waves per workgroup
     constexpr int NT = NW * 64;
     constexpr int NPIECE = (11 + NW - 1) / NW;             // LDS-DMA pieces every wave issues per unit (dummies included)
@@ -587,6 +721,27 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
                         *reinterpret_cast<uint2*>(park + (qb * 6 + jj) / 2 * 1024 + ((qb * 6 + jj) & 1) * 8) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
                 } else {
                     const int q = q0 + qb * 32 + col;
+                    if constexpr (PROJ) {                      // write-through (sc0 sc1): the projecting workgroup may sit on another XCD
+                        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, 0x80000000u, 0x00020000);
+                        if (q < p.N) {
+                            const int off = (int)((((size_t)b * p.N + q) * p.out_ld + h * D) * 2);
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const v2u v = {pk[2 * jj], pk[2 * jj + 1]};
+                                __builtin_amdgcn_raw_buffer_store_b64(v, rs_o, off + (8 * jj + 4 * hi) * 2, 0, AUX_WT);
+                            }
+                        }
+                        if (lane < 32) {
+#pragma unroll
+                            for (int hq = 0; hq < 2; ++hq) {
+                                const int qt = q0 + qb * 32 + 16 * hq + (lane & 15);
+                                if (qt < p.N) {
+                                    const v2u v = {pk[8 + 2 * hq], pk[9 + 2 * hq]};
+                                    __builtin_amdgcn_raw_buffer_store_b64(v, rs_o, (int)((((size_t)b * p.N + qt) * p.out_ld + h * D + 32 + 4 * (lane >> 4)) * 2), 0, AUX_WT);
+                                }
+                            }
+                        }
+                    } else {
                     if (q < p.N) {
                         bf16_t* orow = p.out + ((size_t)b * p.N + q) * p.out_ld + h * D;
 #pragma unroll
@@ -601,6 +756,7 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
                                 *reinterpret_cast<uint2*>(p.out + ((size_t)b * p.N + qt) * p.out_ld + h * D + 32 + 4 * (lane >> 4)) =
                                     make_uint2(pk[8 + 2 * hq], pk[9 + 2 * hq]);
                         }
+                    }
                     }
                 }
             }
@@ -641,6 +797,20 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
         }
         }
     }
+    if constexpr (PROJ) {
+        __shared__ int s_ticket;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's write-through O stores have been acknowledged
+        __syncthreads();                                        // ... everybody's in the workgroup (and the loop's LDS is dead)
+        int* counter = p.proj_counters + b * (int)gridDim.x + wx;
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket == p.H - 1) {                              // the last head of this (batch, 256-row block): all 320 channels of O are in memory
+            if (tid == 0) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef PROJ_T_SKIP_GEMM        // (timing probe: hand-off only)
+            attn_out_proj<F16>(p, b, wx * NT, min(NT, p.N - wx * NT), smem);
+#endif
+        }
+    }
     if ((VAR & 4096) && lane == 0) {       // (the kernel's real output is garbage in this variant: the counters overwrite its head)
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.out);
         atomicAdd(dbg + 0, tm_loop); atomicAdd(dbg + 1, tm_slots); atomicAdd(dbg + 2, tm_check); atomicAdd(dbg + 3, tm_sync);
@@ -655,6 +825,7 @@ int launch_attn40(const AttnParams& p, hipStream_t s) {
     constexpr int NW = (VAR & 32768) ? 8 : 4;
     constexpr int PARKB = NW * ((VAR & 8192) ? PARK_T : PARK) / 4;
     constexpr int LDS_BYTES = (VAR & 512) ? 100 * 1024 : (VAR & 128) ? NRING * BUF_D + PARKB + 1024 : 2 * BUF + PARKB;
+    static_assert(!(VAR & 1048576) || LDS_BYTES >= PJ_LDS, "the out-projection's chunk buffers must fit the loop's LDS");
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return imd_set_error("attention(d=40): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -738,6 +909,10 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
 #endif
         case 10:
         default:
+            if (p.proj_w != nullptr) {      // fused out-projection (validated by imd_launch_attention)
+                if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 1048576>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 1048576>(p, s);
+                return h ? launch_attn40<true, 8, 1 | 8192 | 1048576>(p, s) : launch_attn40<false, 8, 1 | 8192 | 1048576>(p, s);
+            }
             if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192>(p, s);
             return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
     }

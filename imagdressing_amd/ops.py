@@ -96,6 +96,7 @@ def clear_workspaces():
     _ws.clear()
     _splitk_ws.clear()
     _splitk_cnt.clear()
+    _proj_cnt.clear()
     for fn in _clear_hooks:
         fn()
 
@@ -395,9 +396,35 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1
 ATTN_EVENT_HOOK = None
 
 
+# the out-projection of the 64x64-level attention layers inside the attention launch (ABI v7, attention_d40.hip PROJ): the level-0
+# hybrid block = two launches (norm1 + q/k/v, attention + out-projection + residual).  OPT-IN (IMD_FUSED_OUT_PROJ=1): correct and
+# tested, but measured 7.5 % SLOWER end to end than the three-launch form (profiles/r3ao_*, r3ap_*)
+FUSED_OUT_PROJ = _os.environ.get("IMD_FUSED_OUT_PROJ", "0") == "1"
+
+
+def attention_proj_supported(H: int, N: int, D: int) -> bool:
+    """Can imd_attention carry the block's out-projection (ABI v7)?  Head dim 40, 8 heads, N >= 512: the 64x64-level blocks."""
+    return D == 40 and H * D == 320 and N >= 512
+
+
+_proj_cnt: Dict[Tuple, torch.Tensor] = {}
+
+
+def proj_counters(n: int, device) -> torch.Tensor:
+    """Zeroed arrival counters of the fused out-projection (one per batch entry and 256-row block); every launch leaves them zero."""
+    key = (str(device), _stream())
+    t = _proj_cnt.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 4096), dtype=torch.int32, device=device)
+        _proj_cnt[key] = t
+    return t
+
+
 def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=None, scale2=None,
-              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False, k_pad_one=False):
-    """``k_pad_one``: k1 (and k2) came from :func:`k_buffer`, i.e. their pad column D holds 1.0 (see the header)."""
+              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False, k_pad_one=False, proj=None):
+    """``k_pad_one``: k1 (and k2) came from :func:`k_buffer`, i.e. their pad column D holds 1.0 (see the header).
+    ``proj`` = (w [C, C], bias [C] fp32 | None, residual [B, N, C] | None, proj_out [B, N, C]): the out-projection fused into the
+    launch (:func:`attention_proj_supported`); returns proj_out then."""
     ensure_device(q.device)
     p = L.AttnParams()
     dt = q.dtype
@@ -412,6 +439,18 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
     p.out_ld = H * D if out_ld is None else out_ld
     p.causal = int(causal)
     p.k_pad_one = int(bool(k_pad_one))
+    ret = out
+    if proj is not None:
+        pw, pb, pres, pout = proj
+        Cc = H * D
+        if pw.numel() != Cc * Cc or pout.numel() != B * N * Cc or (pres is not None and pres.numel() != B * N * Cc):
+            raise L.ImdError(f"attention: fused out-projection operands do not match B={B} N={N} C={Cc}")
+        p.proj_w, p.proj_b = _dev(pw, dt, "proj_w"), _opt(pb, torch.float32, "proj_b")
+        p.proj_res, p.proj_out = _opt(pres, dt, "proj_res"), _dev(pout, dt, "proj_out")
+        p.proj_res_ld = p.proj_out_ld = Cc
+        p.proj_counters = proj_counters(B * ((N + 255) // 256), q.device).data_ptr()
+        ret = pout
+        _count("gemm", 2.0 * B * N * Cc * Cc)
     if FLOP_COUNTER is not None:          # (reads scale2 back: counting mode only)
         rows2 = 0 if (k2 is None or scale2 is None) else int((scale2 != 0).sum().item())
         _count("attention", 4.0 * H * N * D * (B * L1 * (0.5 if causal else 1.0) + rows2 * L2))
@@ -422,9 +461,9 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
         L.check(L.load().imd_attention(C.byref(p), _stream()))
         e1.record()
         hook["events"].append((e0, e1))
-        return out
+        return ret
     L.check(L.load().imd_attention(C.byref(p), _stream()))
-    return out
+    return ret
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 6
+#define IMD_ABI_VERSION 7
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -103,6 +103,16 @@ typedef struct imd_attn_params {
                           * D = 40: the slot through which the deferred row maximum enters the QK^T MFMA).  The kernels that
                           * stage K through registers write that 1 themselves (0 or 1 in memory are both fine); with the
                           * guarantee the d = 40 kernel may stage K / V^T by LDS-DMA, which cannot patch data in flight. */
+    /* Fused out-projection (ABI v7; head dim 40 with H * D == 320 and N >= 512 only -- the UNet's 64x64-level blocks): when proj_w is
+     * given the launch also computes  proj_out = proj_res + proj_b + out . proj_w^T  (Attention.to_out[0] + the block residual,
+     * attention_processor.py:614-622), i.e. the hybrid block's third launch disappears.  `out` is still written (it is the hand-off
+     * buffer between the heads of a row block: stored write-through, read back by the head that finishes last). */
+    const uint16_t* proj_w;   /* NULL, or [H*D, H*D] row-major (out channel, in channel) */
+    const float* proj_b;      /* [H*D] or NULL */
+    const uint16_t* proj_res; /* [B, N, proj_res_ld] or NULL */
+    uint16_t* proj_out;       /* [B, N, proj_out_ld] */
+    int proj_res_ld, proj_out_ld;
+    int* proj_counters;       /* >= B * ceil(N / 256) ints, ZERO on entry, left zero (one per batch entry and 256-row block) */
 } imd_attn_params;
 
 /* Fused feed-forward of a transformer block on the 64x64 level (ff_fused.hip), C = 320, inner = 1280:

@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 def test_binding_covers_header(lib):
     from imagdressing_amd import _lib
     assert sorted(_lib.SYMBOLS) == declared_functions()
-    assert lib.imd_abi_version() == 6
+    assert lib.imd_abi_version() == 7
 
 
 def header_struct_fields(name):

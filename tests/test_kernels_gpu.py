@@ -664,6 +664,58 @@ def test_attention_d40_kernel_variants(ops, N, L1, L2, pad_one, variant, dt):
     assert_close(out, ref, atol=1e-2 if dt == torch.float16 else 2e-2, rtol=2e-2, what=f"attention d40 variant {variant}")
 
 
+@pytest.mark.parametrize("pad_one", [True, False])
+@pytest.mark.parametrize("B,N,L1,L2", [(2, 640, 640, 330), (3, 1000, 1000, 1000), (2, 512, 700, 0), (4, 4096, 4096, 4096)])
+@DTS
+def test_attention_d40_fused_out_projection(ops, B, N, L1, L2, pad_one, dt):
+    """ABI v7: the block's out-projection (to_out[0] + bias + residual, attention_processor.py:614-622) inside the attention launch --
+    heads of a 256-row block joined through write-through O tiles and an arrival counter, the last head projects.  == the same
+    attention followed by imd_conv_gemm: the O buffer bit for bit, the projection up to fp32 summation order; ragged row blocks
+    (N = 1000, 640), garment rows and plain rows in one launch, repeated launches (counters left at zero)."""
+    D, H = 40, 8
+    Cc = H * D
+    dpk, dpv = ops.attn_padded_dims(D)
+    q = rnd(1, B, N, Cc).to(dt)
+    k1 = rnd(2, B, L1, Cc).to(dt); v1 = rnd(3, B, L1, Cc).to(dt)
+    wo = rnd(6, Cc, Cc, scale=Cc ** -0.5).to(dt); bo = rnd(7, Cc); res = rnd(8, B, N, Cc).to(dt)
+    scale = D ** -0.5 * math.log2(math.e)
+
+    def kbuf(x):
+        h = to_heads(x, H, dpk, dt=dt)
+        if pad_one:
+            h[..., D] = 1.0
+        return dev(h)
+    kw = {}
+    if L2:
+        k2 = rnd(4, 1, L2, Cc).to(dt); v2 = rnd(5, 1, L2, Cc).to(dt)
+        s2 = torch.tensor([0.9] + [0.0] * (B - 1)) if B < 4 else torch.tensor([1.0, 1.0, 0.0, 0.0])
+        kw = dict(k2=kbuf(k2), v2t=dev(to_heads_t(v2, H, dpv, ops.pad64(L2), dt=dt)), scale2=dev(s2), L2=L2, L2P=ops.pad64(L2), kv2_bdiv=B)
+    args = (dev(to_heads(q, H, dpk, scale, dt=dt)), kbuf(k1), dev(to_heads_t(v1, H, dpv, ops.pad64(L1), dt=dt)))
+    common = dict(B=B, H=H, N=N, D=D, L1=L1, L1P=ops.pad64(L1), k_pad_one=pad_one, **kw)
+    assert ops.attention_proj_supported(H, N, D)
+    o_plain = torch.empty(B, N, Cc, dtype=dt, device="cuda")
+    ops.attention(*args, o_plain, **common)
+    two = ops.linear(o_plain.view(B * N, Cc), dev(wo), dev(bo), res=dev(res).view(B * N, Cc)).view(B, N, Cc)
+    exact = o_plain.float() @ dev(wo).float().t() + dev(bo) + dev(res).float()
+    for rep in range(3):
+        o_f = torch.full((B, N, Cc), float("nan"), dtype=dt, device="cuda")
+        fused = torch.full((B, N, Cc), float("nan"), dtype=dt, device="cuda")
+        got = ops.attention(*args, o_f, proj=(dev(wo), dev(bo), dev(res), fused), **common)
+        assert got is fused
+        torch.cuda.synchronize()
+        assert torch.equal(o_f, o_plain), "the O hand-off buffer differs from the plain launch"
+        assert_close(fused, exact, atol=3e-2 if dt == bf16 else 6e-3, rtol=1e-2, what=f"fused out-projection (launch {rep})")
+        assert_close(fused, two.float(), atol=3e-2 if dt == bf16 else 6e-3, rtol=1e-2, what="fused vs attention + imd_conv_gemm")
+        assert int(ops.proj_counters(1, fused.device).abs().max()) == 0
+    # no bias / no residual
+    f2 = torch.empty(B, N, Cc, dtype=dt, device="cuda")
+    ops.attention(*args, torch.empty_like(o_plain), proj=(dev(wo), None, None, f2), **common)
+    assert_close(f2, o_plain.float() @ dev(wo).float().t(), atol=3e-2 if dt == bf16 else 6e-3, rtol=1e-2, what="fused out-projection, bare")
+    with pytest.raises(ops.L.ImdError):          # other head dims keep the separate launch
+        ops.attention(dev(rnd(1, 1, 8, 96, 80).to(dt)), dev(rnd(2, 1, 8, 96, 80).to(dt)), dev(rnd(3, 1, 8, 80, 128).to(dt)), torch.empty(1, 96, 640, dtype=dt, device="cuda"),
+                      B=1, H=8, N=96, D=80, L1=96, L1P=128, proj=(dev(rnd(6, 640, 640).to(dt)), None, None, torch.empty(1, 96, 640, dtype=dt, device="cuda")))
+
+
 @DTS
 def test_attention_shared_kv_batch_div(ops, dt):
     """text K/V computed once per prompt and shared by groups of batch rows (kv batch = b // bdiv)."""

@@ -113,14 +113,18 @@ def check_rows(got, ref, dt, what, spiked=False):
 
 
 @DT
+@pytest.mark.parametrize("fused_out_proj", [False, True], ids=["three_launches", "two_launches"])
 @pytest.mark.parametrize("name", ["hybrid_d40_n4096", "hybrid_d40_spike"])
 @torch.no_grad()
-def test_hybrid_processor_benchmarked_shape_vs_reference_golden(golden_full, name, dt):
+def test_hybrid_processor_benchmarked_shape_vs_reference_golden(golden_full, name, dt, fused_out_proj, monkeypatch):
     """N = M = 4096, C = 320 is the level-0 shape bench.py's roofline times: N >= 512 dispatches the two-query-blocks-per-wave
     instantiation of the fused kernel, with the garment phase, against outputs of the REFERENCE source
     (adapter/attention_processor.py:531-627).  The spiked case (N = 840, M = 700, one image and one garment token scaled x4 late in the
     sequences: hundreds of rows meet a logit ~10 above their running maximum) forces the kernel's deferred-max redo / rescale path on that instantiation and ends in a ragged tile."""
     from imagdressing_amd.adapter import attention_processor as A
+    from imagdressing_amd import ops
+    # two_launches: to_out[0] + bias inside the attention launch (ABI v7, ops.FUSED_OUT_PROJ; the north star's fused hybrid block)
+    monkeypatch.setattr(ops, "FUSED_OUT_PROJ", fused_out_proj)
     c = golden_full[name]
     i = hybrid_inputs(c)
     attn = make_attn(i, c["heads"], dt)
