@@ -11,7 +11,7 @@ import torch
 from imagdressing_amd import ops
 
 CFGS = [0, 4, 2, 1, 5, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21]      # 12-15: row-resident kernels (K = 320 / 640 / 1280 linears, 320 -> 960 qkv), 16: 256^2 LDS-DMA tile kernel; refused elsewhere
-SPLITS = [1, 2, 3, 4, 6, 8]
+SPLITS = [1, 2, 3, 4, 6, 8, 12, 16]
 
 
 def collect_shapes(args, dt):
