@@ -32,7 +32,6 @@ static_assert(PATCH2_LDS >= EROWS2 * CLD2 * 4, "the epilogue tile must fit the m
 // MFMA column (lane & 31) -> pixel of a 2 x 16 pixel block: conv_patch.hip's permutation (conflict-free ds_read_b128 groups)
 __device__ constexpr unsigned char kColPix2[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7,
                                                    30, 31, 16, 17, 22, 23, 24, 25, 26, 27, 28, 29, 18, 19, 20, 21};
-template <int N> __device__ __forceinline__ void dma_wait_keep() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <bool F16>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch2_kernel(const ConvGemmParams p) {
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch2_kernel(const ConvGemmPa
             }
             // the next tap's weight pieces have landed: everything but this tap's two pieces (and, at taps 5 and 6, the six patch
             // pieces issued behind them at tap 5) may stay in flight
-            if (t == 5 || t == 6) dma_wait_keep<8>(); else dma_wait_keep<2>();
+            if (t == 5 || t == 6) dma_wait_keep_n<8>(); else dma_wait_keep_n<2>();
             __syncthreads();
         }
     }

@@ -160,7 +160,6 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const ConvGemmParams p
 // workgroups with two.  Same bytes in flight per CU, but each workgroup's wait is one tile further behind its issue: -8...-22 % on the
 // large linears on one box (profiles/r3ab_ring_depth_big_linears.txt; five stages = one workgroup per CU is slower than either).
 constexpr int G1_BM = 128, G1_BN = 128, G1_BK = 32;
-template <int N> __device__ __forceinline__ void dma_wait_keep_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int G1_STAGE = (G1_BM + G1_BN) * G1_BK * 2;      // 16384
 constexpr int G1_CLD = G1_BN + 4, G1_EROWS = 64;
 static_assert(3 * G1_STAGE >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");

@@ -27,6 +27,8 @@ __device__ __forceinline__ void dma16_nonop(const v4i_t& rsrc, uint32_t lds_addr
                  : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// all but the N youngest pieces of this wave (N a compile-time constant; the named forms below are older call sites)
+template <int N> __device__ __forceinline__ void dma_wait_keep_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void dma_wait_keep2() { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }   // all but the 2 youngest pieces
 __device__ __forceinline__ void dma_wait_keep3() { asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }   // all but the 3 youngest pieces
 __device__ __forceinline__ void dma_wait_keep4() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }   // all but the 4 youngest pieces
