@@ -103,6 +103,31 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const bf16_t* a, int a_ld, 
     }
 }
 
+// out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r] (+ b_add[r]): the skip concat of an up block (+ the ControlNet residual) in ONE launch
+template <bool F16>
+__global__ __launch_bounds__(256) void concat2_kernel(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows) {
+    const int va = Ca / 8, vpr = (Ca + Cb) / 8;
+    const long total = rows * vpr;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long r = i / vpr;
+        const int v = (int)(i - r * vpr);
+        uint4 val;
+        if (v < va) val = *reinterpret_cast<const uint4*>(a + r * Ca + v * 8);
+        else {
+            const long off = r * Cb + (v - va) * 8;
+            val = *reinterpret_cast<const uint4*>(b + off);
+            if (b_add) {
+                float x[8], y[8];
+                unpack8<F16>(val, x);
+                unpack8<F16>(*reinterpret_cast<const uint4*>(b_add + off), y);
+                val = make_uint4(El<F16>::pack2(x[0] + y[0], x[1] + y[1]), El<F16>::pack2(x[2] + y[2], x[3] + y[3]),
+                                 El<F16>::pack2(x[4] + y[4], x[5] + y[5]), El<F16>::pack2(x[6] + y[6], x[7] + y[7]));
+            }
+        }
+        *reinterpret_cast<uint4*>(out + r * (long)(Ca + Cb) + v * 8) = val;
+    }
+}
+
 // out[r] = table[ids[r]] + pos[r % T]      (8 channels per thread; ids outside [0, vocab) read row 0)
 template <bool F16>
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const bf16_t* table, int vocab, const bf16_t* pos, int T, const int64_t* ids,
@@ -242,6 +267,16 @@ int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long r
     if (C % 8 || a_ld % 8 || out_ld % 8) return imd_set_error("copy2d: C and row strides must be multiples of 8");
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, s, a, a_ld, out, out_ld, rows, C);
     return imd_check_launch("copy2d");
+}
+
+int imd_launch_concat2(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows, int dtype, hipStream_t s) {
+    if (rows <= 0 || Ca <= 0 || Cb <= 0) return imd_set_error("concat2: empty tensor");
+    if (Ca % 8 || Cb % 8) return imd_set_error("concat2: channel counts must be multiples of 8 (got %d + %d)", Ca, Cb);
+    const long work = rows * ((Ca + Cb) / 8);
+    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(concat2_kernel<true>, dim3(grid_for(work)), dim3(256), 0, s, a, Ca, b, Cb, b_add, out, rows);
+    else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(concat2_kernel<false>, dim3(grid_for(work)), dim3(256), 0, s, a, Ca, b, Cb, b_add, out, rows);
+    else return imd_set_error("concat2: unknown dtype %d", dtype);
+    return imd_check_launch("concat2");
 }
 
 int imd_launch_f32_to_16(const float* a, bf16_t* out, long n, int dtype, hipStream_t s) {

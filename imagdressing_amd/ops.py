@@ -696,12 +696,9 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor, b_add: Optional[torch.Tens
     dt = a.dtype
     out = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=dt, device=a.device)
     lib = L.load()
-    L.check(lib.imd_copy2d(_dev(a, dt, "a"), Ca, out.data_ptr(), Ca + Cb, rows, Ca, _stream()))
-    if b_add is None:
-        L.check(lib.imd_copy2d(_dev(b, dt, "b"), Cb, out.data_ptr() + 2 * Ca, Ca + Cb, rows, Cb, _stream()))
-    else:
-        L.check(lib.imd_add(_dev(b, dt, "b"), Cb, _dev(b_add, dt, "b_add"), Cb, out.data_ptr() + 2 * Ca, Ca + Cb,
-                            rows, Cb, 1.0, _code(a, "a"), _stream()))
+    if b.numel() != rows * Cb or (b_add is not None and b_add.numel() != rows * Cb):
+        raise L.ImdError(f"concat_channels: operands disagree on the row count ({rows} rows of {Ca} + {Cb} channels)")
+    L.check(lib.imd_concat2(_dev(a, dt, "a"), Ca, _dev(b, dt, "b"), Cb, _opt(b_add, dt, "b_add"), out.data_ptr(), rows, _code(a, "a"), _stream()))
     return out
 
 
