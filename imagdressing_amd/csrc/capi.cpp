@@ -194,9 +194,9 @@ int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows
     return imd_launch_copy2d(a, a_ld, out, out_ld, rows, C, (hipStream_t)stream);
 }
 
-int imd_concat2(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint16_t* b_add, uint16_t* out, long rows, int dtype, void* stream) {
+int imd_concat2(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint16_t* b_add, uint16_t* out, long rows, long b_rows, int dtype, void* stream) {
     IMD_REQUIRE(a && b && out, "concat2: null pointer");
-    return imd_launch_concat2(a, Ca, b, Cb, b_add, out, rows, dtype, (hipStream_t)stream);
+    return imd_launch_concat2(a, Ca, b, Cb, b_add, out, rows, b_rows, dtype, (hipStream_t)stream);
 }
 
 int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream) {

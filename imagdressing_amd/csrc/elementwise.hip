@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void copy2d_kernel(const bf16_t* a, int a_ld, 
 
 // out[r, 0:Ca] = a[r], out[r, Ca:Ca+Cb] = b[r] (+ b_add[r]): the skip concat of an up block (+ the ControlNet residual) in ONE launch
 template <bool F16>
-__global__ __launch_bounds__(256) void concat2_kernel(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows) {
+__global__ __launch_bounds__(256) void concat2_kernel(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows, long b_rows) {
     const int va = Ca / 8, vpr = (Ca + Cb) / 8;
     const long total = rows * vpr;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void concat2_kernel(const bf16_t* a, int Ca, c
         if (v < va) val = *reinterpret_cast<const uint4*>(a + r * Ca + v * 8);
         else {
             const long off = r * Cb + (v - va) * 8;
-            val = *reinterpret_cast<const uint4*>(b + off);
+            val = *reinterpret_cast<const uint4*>(b + (r % b_rows) * Cb + (v - va) * 8);     // (b_rows < rows: b repeats, e.g. one copy for both CFG halves)
             if (b_add) {
                 float x[8], y[8];
                 unpack8<F16>(val, x);
@@ -269,12 +269,14 @@ int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long r
     return imd_check_launch("copy2d");
 }
 
-int imd_launch_concat2(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows, int dtype, hipStream_t s) {
+int imd_launch_concat2(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows, long b_rows, int dtype, hipStream_t s) {
     if (rows <= 0 || Ca <= 0 || Cb <= 0) return imd_set_error("concat2: empty tensor");
+    if (b_rows <= 0) b_rows = rows;
+    if (rows % b_rows) return imd_set_error("concat2: b_rows (%ld) must divide rows (%ld)", b_rows, rows);
     if (Ca % 8 || Cb % 8) return imd_set_error("concat2: channel counts must be multiples of 8 (got %d + %d)", Ca, Cb);
     const long work = rows * ((Ca + Cb) / 8);
-    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(concat2_kernel<true>, dim3(grid_for(work)), dim3(256), 0, s, a, Ca, b, Cb, b_add, out, rows);
-    else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(concat2_kernel<false>, dim3(grid_for(work)), dim3(256), 0, s, a, Ca, b, Cb, b_add, out, rows);
+    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(concat2_kernel<true>, dim3(grid_for(work)), dim3(256), 0, s, a, Ca, b, Cb, b_add, out, rows, b_rows);
+    else if (dtype == IMD_DTYPE_BF16) hipLaunchKernelGGL(concat2_kernel<false>, dim3(grid_for(work)), dim3(256), 0, s, a, Ca, b, Cb, b_add, out, rows, b_rows);
     else return imd_set_error("concat2: unknown dtype %d", dtype);
     return imd_check_launch("concat2");
 }

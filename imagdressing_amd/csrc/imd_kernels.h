@@ -63,5 +63,5 @@ int imd_launch_embed_tokens(const bf16_t* table, int vocab, const bf16_t* pos, i
 int imd_launch_vit_assemble(const bf16_t* patches, const bf16_t* cls, const bf16_t* pos, bf16_t* out, int B, int P, int C, int dtype, hipStream_t s);
 int imd_launch_lincomb(const float* const* xs, const float* coefs, int n, float* out, long numel, hipStream_t s);
 int imd_launch_copy2d(const bf16_t* a, int a_ld, bf16_t* out, int out_ld, long rows, int C, hipStream_t s);
-int imd_launch_concat2(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows, int dtype, hipStream_t s);
+int imd_launch_concat2(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, long rows, long b_rows, int dtype, hipStream_t s);
 int imd_launch_f32_to_16(const float* a, bf16_t* out, long n, int dtype, hipStream_t s);

@@ -225,7 +225,7 @@ class PipelineBase:
             down = mid = None
             if control is not None:
                 down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, ctrl_scale * (keeps[0] if i is None else keeps[i]))
-            eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid)
+            eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid, cfg_pair=True)     # x_in = [z; z]: both halves see the same latent
             kw = {}
             if inp is not None:
                 kw = dict(mask=inp["mask"], z_img=inp["z_img"], noise=inp["noise"])
@@ -282,7 +282,7 @@ class PipelineBase:
                 down = mid = None
                 if control is not None:
                     down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, ctrl_scale * keeps[i])
-                eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid)
+                eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid, cfg_pair=True)
                 z = sch.step_guided(eps.view(2 * B, HW, Cl), z, float(guidance_scale))
                 # emit the next 16-bit UNet input (both CFG halves) from z: the fused step with eps = 0, alpha = 1 is the identity on z
                 ops.ddim_cfg_step(z, ops.workspace("zero_eps", (2 * B, HW, Cl), torch.float32, dev), x_in.view(2 * B, HW, 8),

@@ -137,6 +137,7 @@ FUSED_FF = True            # engines run norm3 -> GEGLU feed-forward -> + residu
 FUSED_FF_MIN_ROWS = 24576  # below this the 128-row workgroups cannot fill the chip (one per CU at 32768 rows) and the tiled kernels win
 import os as _os
 FUSED_GN_STATS = _os.environ.get("IMD_FUSED_GN_STATS", "1") != "0"   # 3x3 convs on the halo-patch kernel emit the GroupNorm statistics of their output from the epilogue (A/B switch)
+CFG_PAIR_DEDUP = _os.environ.get("IMD_CFG_PAIR_DEDUP", "1") != "0"   # sampling loop: conv_in + first resnet once for the two identical CFG halves (A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 _GEMM_TABLE = None
@@ -696,9 +697,22 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor, b_add: Optional[torch.Tens
     dt = a.dtype
     out = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=dt, device=a.device)
     lib = L.load()
-    if b.numel() != rows * Cb or (b_add is not None and b_add.numel() != rows * Cb):
-        raise L.ImdError(f"concat_channels: operands disagree on the row count ({rows} rows of {Ca} + {Cb} channels)")
-    L.check(lib.imd_concat2(_dev(a, dt, "a"), Ca, _dev(b, dt, "b"), Cb, _opt(b_add, dt, "b_add"), out.data_ptr(), rows, _code(a, "a"), _stream()))
+    b_rows = b.numel() // Cb            # b may hold HALF the rows: one skip tensor for both (identical) halves of a CFG batch
+    if b_rows * Cb != b.numel() or b_rows == 0 or rows % b_rows or (b_add is not None and b_add.numel() != rows * Cb):
+        raise L.ImdError(f"concat_channels: operands disagree on the row count ({rows} rows of {Ca} + {Cb} channels, b has {b_rows})")
+    L.check(lib.imd_concat2(_dev(a, dt, "a"), Ca, _dev(b, dt, "b"), Cb, _opt(b_add, dt, "b_add"), out.data_ptr(), rows, b_rows, _code(a, "a"), _stream()))
+    return out
+
+
+def repeat_batch(x: torch.Tensor, times: int = 2) -> torch.Tensor:
+    """cat([x] * times, dim=0) for a contiguous NHWC tensor (strided 2-D copies)."""
+    ensure_device(x.device)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    out = torch.empty((x.shape[0] * times,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    src = _dev(x, x.dtype, "x")
+    for i in range(times):
+        L.check(L.load().imd_copy2d(src, Cc, out.data_ptr() + 2 * i * rows * Cc, Cc, rows, Cc, _stream()))
     return out
 
 

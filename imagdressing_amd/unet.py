@@ -414,11 +414,17 @@ class _Encoder(PretrainedMixin):
         e = ops.linear(e, self.time_lin2.weight, self.time_lin2.bias, act=ops.ACT_SILU)
         return ops.linear(e, self.temb_proj.weight, self.temb_proj.bias, out_f32=True)     # [B, sum(Cout)] fp32
 
-    def _run_down(self, x, temb_all, ehs, cak):
-        skips = [x]
+    def _run_down(self, x, temb_all, ehs, cak, pair_skip=None):
+        """``pair_skip``: the caller has already run conv_in and the first resnet on ONE half of a CFG batch whose halves are identical
+        up to there (``x`` = that resnet's output repeated for both halves, ``pair_skip`` = the half-batch conv_in output)."""
+        skips = [x if pair_skip is None else pair_skip]
+        first = pair_skip is not None
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
-                x = r(x, temb_all)
+                if first:
+                    first = False                       # (already applied by the caller)
+                else:
+                    x = r(x, temb_all)
                 if blk.attentions:
                     x = blk.attentions[j](x, ehs, cak)
                 skips.append(x)
@@ -504,14 +510,22 @@ class UNet2DConditionModel(_Encoder):
     def forward_nhwc(self, x: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor,
                      cross_attention_kwargs: Optional[dict] = None,
                      down_block_additional_residuals: Optional[List[torch.Tensor]] = None,
-                     mid_block_additional_residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x [B, H, W, 8] bf16 (latent channels zero-padded to 8) -> eps [B, H*W, 4] fp32."""
+                     mid_block_additional_residual: Optional[torch.Tensor] = None, cfg_pair: bool = False) -> torch.Tensor:
+        """x [B, H, W, 8] bf16 (latent channels zero-padded to 8) -> eps [B, H*W, 4] fp32.
+        ``cfg_pair``: the caller guarantees x[B/2:] == x[:B/2] (the CFG batch of the sampling loop: the reference feeds the SAME latent to
+        its cond and uncond UNet calls, IMAGDressing_v1_pipeline.py:483-512).  conv_in and the first resnet see neither the text nor the
+        garment, so their outputs are identical for the two halves: they run on one half and the result is repeated."""
         cak = dict(cross_attention_kwargs or {})
         B, H, W, _ = x.shape
         ehs = encoder_hidden_states
         temb_all = self._time_embed(timestep, B, x.device)
-        h = self.conv_in(x)
-        h, skips = self._run_down(h, temb_all, ehs, cak)
+        if cfg_pair and B % 2 == 0 and ops.CFG_PAIR_DEDUP:
+            h0 = self.conv_in(x[:B // 2])
+            h = ops.repeat_batch(self.down_blocks[0].resnets[0](h0, temb_all))
+            h, skips = self._run_down(h, temb_all, ehs, cak, pair_skip=h0)
+        else:
+            h = self.conv_in(x)
+            h, skips = self._run_down(h, temb_all, ehs, cak)
         h = self._run_mid(h, temb_all, ehs, cak)
         if mid_block_additional_residual is not None:
             h = ops.add(h, mid_block_additional_residual)

@@ -289,8 +289,10 @@ int imd_vit_assemble(const uint16_t* patches, const uint16_t* cls, const uint16_
 int imd_lincomb(const float* const* xs, const float* coefs, int n, float* out, long numel, void* stream);
 int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows, int C, void* stream);
 /* out[r, 0:Ca] = a[r, :], out[r, Ca:Ca+Cb] = b[r, :] (+ b_add[r, :] when given): torch.cat([x, skip (+ ControlNet residual)], dim=1) of
- * an up block (diffusers UNet2DConditionModel up path; ..._pipeline_ipa_controlnet.py:676-688) in one launch; contiguous rows. */
-int imd_concat2(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint16_t* b_add, uint16_t* out, long rows, int dtype, void* stream);
+ * an up block (diffusers UNet2DConditionModel up path; ..._pipeline_ipa_controlnet.py:676-688) in one launch; contiguous rows.
+ * b_rows: 0 (= rows), or a divisor of rows -- b then holds b_rows rows and row r reads b[r % b_rows] (one skip tensor serving both
+ * halves of a CFG batch whose halves are identical up to that layer). */
+int imd_concat2(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint16_t* b_add, uint16_t* out, long rows, long b_rows, int dtype, void* stream);
 /* fp32 -> 16-bit element cast (round to nearest even). */
 int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream);
 
