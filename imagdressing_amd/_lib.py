@@ -11,16 +11,27 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IMD_LIB_PATH") or os.path.join(_HERE, "libimagdressing_hip.so")     # override: A/B of two builds
 
+ABI_VERSION = 8
+
 u16p = C.POINTER(C.c_uint16)
 f32p = C.POINTER(C.c_float)
+
+
+class _Sized(C.Structure):
+    """Parameter blocks of ABI v8 start with ``struct_bytes`` = sizeof(the struct as THIS binding lays it out); the library refuses any
+    other value (a binding that mirrors another header version would otherwise hand it a truncated struct)."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_bytes = C.sizeof(self)
 
 
 class HeadsDest(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("kind", C.c_int), ("DP", C.c_int), ("L", C.c_int), ("scale", C.c_float)]
 
 
-class ConvGemmParams(C.Structure):
-    _fields_ = [
+class ConvGemmParams(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), 
         ("x", C.c_void_p), ("w", C.c_void_p), ("out", C.c_void_p),
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
         ("Cin", C.c_int), ("taps", C.c_int), ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int),
@@ -37,14 +48,14 @@ class ConvGemmParams(C.Structure):
     ]
 
 
-class FfParams(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p),
+class FfParams(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), ("x", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p), ("out", C.c_void_p),
                 ("M", C.c_int), ("C", C.c_int), ("inner", C.c_int), ("x_ld", C.c_int), ("out_ld", C.c_int), ("ln", C.c_int),
                 ("ln_eps", C.c_float), ("dtype", C.c_int)]
 
 
-class AttnParams(C.Structure):
-    _fields_ = [
+class AttnParams(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), 
         ("q", C.c_void_p), ("k1", C.c_void_p), ("v1t", C.c_void_p), ("k2", C.c_void_p), ("v2t", C.c_void_p),
         ("scale2", C.c_void_p), ("out", C.c_void_p),
         ("B", C.c_int), ("H", C.c_int), ("N", C.c_int), ("D", C.c_int),
@@ -56,23 +67,23 @@ class AttnParams(C.Structure):
     ]
 
 
-class GroupNormParams(C.Structure):
-    _fields_ = [
+class GroupNormParams(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), 
         ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("partial", C.c_void_p),
         ("B", C.c_int), ("HW", C.c_int), ("C", C.c_int), ("G", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int),
         ("eps", C.c_float), ("silu", C.c_int), ("dtype", C.c_int), ("nparts", C.c_int),
     ]
 
 
-class LayerNormParams(C.Structure):
-    _fields_ = [
+class LayerNormParams(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), 
         ("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
         ("rows", C.c_int), ("C", C.c_int), ("x_ld", C.c_int), ("y_ld", C.c_int), ("eps", C.c_float), ("dtype", C.c_int),
     ]
 
 
-class DdimParams(C.Structure):
-    _fields_ = [
+class DdimParams(_Sized):
+    _fields_ = [("struct_bytes", C.c_uint32), 
         ("z", C.c_void_p), ("eps", C.c_void_p), ("x_next", C.c_void_p),
         ("B", C.c_int), ("HW", C.c_int),
         ("guidance", C.c_float), ("sqrt_a_t", C.c_float), ("sqrt_1m_a_t", C.c_float),
@@ -138,8 +149,8 @@ def load():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)          # AttributeError if the ABI lost a symbol
             fn.restype, fn.argtypes = res, args
-        if lib.imd_abi_version() != 7:
-            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects 7")
+        if lib.imd_abi_version() != ABI_VERSION:
+            raise ImdError(f"ABI version mismatch: library reports {lib.imd_abi_version()}, binding expects {ABI_VERSION}")
         _lib = lib
     return _lib
 

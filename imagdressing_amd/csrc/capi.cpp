@@ -24,6 +24,10 @@ int imd_check_launch(const char* what) {
 }
 
 #define IMD_REQUIRE(cond, ...) do { if (!(cond)) return imd_set_error(__VA_ARGS__); } while (0)
+// ABI v8: every parameter block starts with the size the CALLER believes it has
+#define IMD_REQUIRE_SIZE(p, what) IMD_REQUIRE((p)->struct_bytes == sizeof(*(p)), \
+    "%s: parameter block is %u bytes in the caller's view, this library (ABI v%d) expects %zu: the binding mirrors another version of include/imagdressing_hip.h (set struct_bytes = sizeof(struct) after zero-initialising it)", \
+    what, (unsigned)(p)->struct_bytes, IMD_ABI_VERSION, sizeof(*(p)))
 
 extern "C" {
 
@@ -41,6 +45,7 @@ int imd_device_check(int device) {
 
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream) {
     IMD_REQUIRE(p != nullptr, "conv_gemm: null params");
+    IMD_REQUIRE_SIZE(p, "conv_gemm");
     IMD_REQUIRE(p->x && p->w, "conv_gemm: null input/weight pointer");
     IMD_REQUIRE(p->mode == IMD_OUT_HEADS || p->out != nullptr, "conv_gemm: null output pointer");
     IMD_REQUIRE(p->Hout > 0 && p->Wout > 0 && p->Hin > 0 && p->Win > 0, "conv_gemm: bad geometry");
@@ -61,6 +66,7 @@ int imd_conv_gemm_auto_split(int M, int N, int K, int cfg) { return imd_conv_gem
 
 int imd_attention(const imd_attn_params* p, void* stream) {
     IMD_REQUIRE(p != nullptr, "attention: null params");
+    IMD_REQUIRE_SIZE(p, "attention");
     IMD_REQUIRE(p->q && p->k1 && p->v1t && p->out, "attention: null q/k/v/out pointer");
     IMD_REQUIRE((p->k2 == nullptr) == (p->v2t == nullptr), "attention: k2 and v2t must be given together");
     IMD_REQUIRE(p->out_ld >= p->H * p->D && p->out_ld % 4 == 0, "attention: bad out_ld %d", p->out_ld);
@@ -69,6 +75,7 @@ int imd_attention(const imd_attn_params* p, void* stream) {
 
 int imd_attention_fp8(const imd_attn_params* p, int eq, int ek, int ev, void* stream) {
     IMD_REQUIRE(p != nullptr, "attention_fp8: null params");
+    IMD_REQUIRE_SIZE(p, "attention_fp8");
     IMD_REQUIRE(p->q && p->k1 && p->v1t && p->out, "attention_fp8: null q/k/v/out pointer");
     IMD_REQUIRE((p->k2 == nullptr) == (p->v2t == nullptr), "attention_fp8: k2 and v2t must be given together");
     IMD_REQUIRE(p->out_ld >= p->H * p->D && p->out_ld % 4 == 0, "attention_fp8: bad out_ld %d", p->out_ld);
@@ -107,24 +114,30 @@ int imd_attn_padded_dims(int D, int* dpk, int* dpv) {
 }
 
 int imd_groupnorm(const imd_groupnorm_params* p, void* stream) {
-    IMD_REQUIRE(p && p->x && p->y && p->gamma && p->beta && p->partial, "groupnorm: null pointer");
+    IMD_REQUIRE(p != nullptr, "groupnorm: null params");
+    IMD_REQUIRE_SIZE(p, "groupnorm");
+    IMD_REQUIRE(p->x && p->y && p->gamma && p->beta && p->partial, "groupnorm: null pointer");
     return imd_launch_groupnorm(*p, (hipStream_t)stream);
 }
 
 int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* coef_b, void* stream) {
-    IMD_REQUIRE(p && p->x && p->gamma && p->beta && p->partial && coef_a && coef_b, "groupnorm_coeffs: null pointer");
+    IMD_REQUIRE(p != nullptr, "groupnorm_coeffs: null params");
+    IMD_REQUIRE_SIZE(p, "groupnorm_coeffs");
+    IMD_REQUIRE(p->x && p->gamma && p->beta && p->partial && coef_a && coef_b, "groupnorm_coeffs: null pointer");
     return imd_launch_groupnorm_coeffs(*p, coef_a, coef_b, (hipStream_t)stream);
 }
 
-int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (p && imd_conv_patch_supported(*p)) ? 1 : 0; }
-int imd_conv_patch2_supported(const imd_conv_gemm_params* p) { return (p && imd_conv_patch2_supported(*p)) ? 1 : 0; }
-int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return p ? imd_conv_patch_stats_parts_of(*p) : 0; }
-int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return (p && imd_gemm_dma_supported(*p)) ? 1 : 0; }
+static bool sized(const imd_conv_gemm_params* p) { return p && p->struct_bytes == sizeof(*p); }      // (queries answer 0 for a foreign layout)
+int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch_supported(*p)) ? 1 : 0; }
+int imd_conv_patch2_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch2_supported(*p)) ? 1 : 0; }
+int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return sized(p) ? imd_conv_patch_stats_parts_of(*p) : 0; }
+int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_gemm_dma_supported(*p)) ? 1 : 0; }
 
-int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (p && (imd_row_linear_supported(*p) || imd_row_linear_k640_supported(*p) || imd_row_linear_k1280_supported(*p) || imd_row_qkv_supported(*p))) ? 1 : 0; }
+int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (sized(p) && (imd_row_linear_supported(*p) || imd_row_linear_k640_supported(*p) || imd_row_linear_k1280_supported(*p) || imd_row_qkv_supported(*p))) ? 1 : 0; }
 
 int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* stream) {
     IMD_REQUIRE(p != nullptr, "row_linear: null params");
+    IMD_REQUIRE_SIZE(p, "row_linear");
     IMD_REQUIRE(p->x && p->w, "row_linear: null input/weight pointer");
     IMD_REQUIRE(p->mode == IMD_OUT_HEADS || p->out != nullptr, "row_linear: null output pointer");
     IMD_REQUIRE(p->Hout > 0 && p->Wout > 0 && p->M > 0 && p->M % (p->Hout * p->Wout) == 0, "row_linear: bad geometry");
@@ -141,13 +154,17 @@ int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* st
 }
 
 int imd_ff_geglu(const imd_ff_params* p, void* stream) {
-    IMD_REQUIRE(p && p->x && p->w1 && p->b1 && p->w2 && p->b2 && p->out, "ff_geglu: null pointer");
+    IMD_REQUIRE(p != nullptr, "ff_geglu: null params");
+    IMD_REQUIRE_SIZE(p, "ff_geglu");
+    IMD_REQUIRE(p->x && p->w1 && p->b1 && p->w2 && p->b2 && p->out, "ff_geglu: null pointer");
     IMD_REQUIRE(!p->ln || p->ln_eps > 0.f, "ff_geglu: LayerNorm needs eps > 0");
     return imd_launch_ff_geglu(*p, (hipStream_t)stream);
 }
 
 int imd_layernorm(const imd_layernorm_params* p, void* stream) {
-    IMD_REQUIRE(p && p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
+    IMD_REQUIRE(p != nullptr, "layernorm: null params");
+    IMD_REQUIRE_SIZE(p, "layernorm");
+    IMD_REQUIRE(p->x && p->y && p->gamma && p->beta, "layernorm: null pointer");
     return imd_launch_layernorm(*p, (hipStream_t)stream);
 }
 
@@ -174,7 +191,9 @@ int imd_softmax_rows(const float* s, int s_ld, uint16_t* p, int p_ld, int rows, 
 }
 
 int imd_ddim_cfg_step(const imd_ddim_params* p, void* stream) {
-    IMD_REQUIRE(p && p->z && p->eps, "ddim_cfg_step: null pointer");
+    IMD_REQUIRE(p != nullptr, "ddim_cfg_step: null params");
+    IMD_REQUIRE_SIZE(p, "ddim_cfg_step");
+    IMD_REQUIRE(p->z && p->eps, "ddim_cfg_step: null pointer");
     IMD_REQUIRE(p->coefs != nullptr || p->sqrt_a_t > 0.f, "ddim_cfg_step: sqrt(alpha_t) must be positive");
     return imd_launch_ddim_cfg_step(*p, (hipStream_t)stream);
 }

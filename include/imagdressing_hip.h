@@ -15,6 +15,10 @@
  *     papered over.
  *   - Activations are NHWC / token-major ([B, H*W, C]) bf16; weights are [N][K] bf16 with
  *     k = (ky*3 + kx) * Cin + ci for 3x3 convolutions.
+ *   - ABI v8: the first field of every parameter block is `struct_bytes` = sizeof(the struct) as the CALLER compiled it.  An
+ *     entry point that receives any other value returns an error instead of reading fields the caller never wrote (the v7 blocks
+ *     grew at the tail; a binding that mirrored an older header handed the library a truncated struct).  Zero-initialise the
+ *     block, set struct_bytes, then fill what you need: every optional pointer is NULL-off.
  */
 #ifndef IMAGDRESSING_HIP_H
 #define IMAGDRESSING_HIP_H
@@ -25,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 7
+#define IMD_ABI_VERSION 8
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -42,6 +46,7 @@ typedef struct imd_heads_dest {
 } imd_heads_dest;
 
 typedef struct imd_conv_gemm_params {
+    uint32_t struct_bytes; /* sizeof(imd_conv_gemm_params) in the caller's view (ABI v8); checked on entry */
     const uint16_t* x; /* NHWC activations (pixel stride x_pix_stride) or [M, K] rows */
     const uint16_t* w; /* [N][K] */
     void* out;         /* bf16 (fp32 when out_f32) [M, out_ld] */
@@ -85,6 +90,7 @@ typedef struct imd_conv_gemm_params {
 #define IMD_SPLITK_COUNTERS 16384
 
 typedef struct imd_attn_params {
+    uint32_t struct_bytes; /* sizeof(imd_attn_params) in the caller's view (ABI v8); checked on entry */
     const uint16_t* q;   /* [B, H, N, DPK], pre-scaled by D^-1/2 * log2(e) */
     const uint16_t* k1;  /* [B1, H, L1, DPK] */
     const uint16_t* v1t; /* [B1, H, DPV, L1P] */
@@ -124,6 +130,7 @@ typedef struct imd_attn_params {
  *   w2 [40 chunks][320 rows][32]: chunk c holds inner channels 32 c .. 32 c + 31 as two 16-groups whose members are stored in
  *      the order 0-3, 8-11, 4-7, 12-15 (the register order of the GEGLU outputs of a lane). */
 typedef struct imd_ff_params {
+    uint32_t struct_bytes; /* sizeof(imd_ff_params) in the caller's view (ABI v8); checked on entry */
     const uint16_t* x;   /* [M, x_ld] block input (un-normalised when ln) -- also the residual */
     const uint16_t* w1;
     const float* b1;
@@ -138,6 +145,7 @@ typedef struct imd_ff_params {
 } imd_ff_params;
 
 typedef struct imd_groupnorm_params {
+    uint32_t struct_bytes; /* sizeof(imd_groupnorm_params) in the caller's view (ABI v8); checked on entry */
     const uint16_t* x; uint16_t* y; const float* gamma; const float* beta;
     float* partial;      /* workspace of imd_groupnorm_workspace_floats() floats */
     int B, HW, C, G, x_ld, y_ld;
@@ -150,6 +158,7 @@ typedef struct imd_groupnorm_params {
 } imd_groupnorm_params;
 
 typedef struct imd_layernorm_params {
+    uint32_t struct_bytes; /* sizeof(imd_layernorm_params) in the caller's view (ABI v8); checked on entry */
     const uint16_t* x; uint16_t* y; const float* gamma; const float* beta;
     int rows, C, x_ld, y_ld;
     float eps;
@@ -157,6 +166,7 @@ typedef struct imd_layernorm_params {
 } imd_layernorm_params;
 
 typedef struct imd_ddim_params {
+    uint32_t struct_bytes; /* sizeof(imd_ddim_params) in the caller's view (ABI v8); checked on entry */
     float* z;             /* [B, HW, 4] fp32 latent state, updated in place */
     const float* eps;     /* [2B, HW, 4] fp32: rows [0,B) cond pass, [B,2B) uncond pass */
     uint16_t* x_next;     /* [2B, HW, 8] bf16 next UNet input (channels 4..7 = 0) or NULL */

@@ -347,9 +347,73 @@ def main_unet():
     print("unet_forward_full.pt", os.path.getsize(os.path.join(OUT, "unet_forward_full.pt")) // 1024, "KiB")
 
 
+@torch.no_grad()
+def main_timesteps():
+    """Fifth fixture file: full-width fp32-oracle UNet forwards at the two ENDS of the DDIM schedule (t = 981: eps ~ z, the first step of
+    the 50-step run; t = 1: the last) for the configs[1] processors (t = 481 is in unet_forward_full.pt), and at t = 981 / 481 / 1 for the
+    configs[2] stack -- LoraRefS + LoRAIP processors (rank 128, 77 text + 4 face tokens) with the pose ControlNet's residuals added,
+    the ControlNet run on the CFG pair in the reference's order (..._ipa_controlnet.py:651-666: row [1] -> cond, row [0] -> uncond).
+    bench.py's `parity` leg and tests/test_fullsize_gpu.py measure the HIP engine against these (tests/unet_fixture.py)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from imagdressing_amd import unet as E
+    from tests.harness_names import hidden_size_of
+    from tests.unet_fixture import fill_ipa_processors, ipa_controlnet_forward_inputs, unet_forward_inputs
+    from . import processors as OP
+    from . import sd15
+    torch.set_num_threads(8)
+    boc = E.SD15_CONFIG["block_out_channels"]
+    cases = {}
+    # ---- configs[1] processors at the ends of the schedule ----
+    d = unet_forward_inputs(64, 64)
+    o = sd15.UNet2DConditionModel({})
+    o.load_state_dict(d["sd"], strict=True)
+    o.set_attn_processor({n: (OP.RefSAttn(n, hidden_size_of(n, boc)) if n.endswith("attn1.processor")
+                              else OP.CAttn(n, hidden_size_of(n, boc), 768)) for n in o.attn_processors.keys()})
+    for n in d["names"]:
+        o.attn_processors[n].to_k_ref.weight.copy_(d["rw"][n]["k"]); o.attn_processors[n].to_v_ref.weight.copy_(d["rw"][n]["v"])
+    refs = dict(kind="unet_forward_timesteps", lh=64, lw=64, digests=d["digests"], torch_version=torch.__version__)
+    for t in (981, 1):
+        unc = o(d["x"], t, d["ehs"])
+        cond = o(d["x"], t, d["ehs"], cross_attention_kwargs={"sa_hidden_states": d["sa"]})
+        refs[f"t{t}"] = dict(out_uncond=unc.clone(), out_cond=cond.clone())
+        print("refs t", t, "uncond std", unc.std().item())
+    cases["refs"] = refs
+    del o
+    # ---- configs[2] stack at t = 981 / 481 / 1 ----
+    d = ipa_controlnet_forward_inputs()
+    o = sd15.UNet2DConditionModel({})
+    o.load_state_dict(d["sd"], strict=True)
+    procs = {n: (OP.LoraRefSAttn(n, hidden_size_of(n, boc), scale=d["ref_scale"], rank=d["rank"], lora_scale=d["lora_scale"])
+                 if n.endswith("attn1.processor") else
+                 OP.LoRAIPAttn(hidden_size_of(n, boc), 768, rank=d["rank"], lora_scale=d["lora_scale"], scale=d["ip_scale"], num_tokens=4))
+             for n in o.attn_processors.keys()}
+    fill_ipa_processors(procs, d)
+    o.set_attn_processor(procs)
+    c = sd15.ControlNetModel({})
+    c.load_state_dict(d["ctrl_sd"], strict=True)
+    ipa = dict(kind="unet_forward_ipa_controlnet", lh=64, lw=64, digests=d["digests"], torch_version=torch.__version__)
+    lmi = torch.cat([d["x"]] * 2)
+    pec = torch.cat([d["ehs_u_text"], d["ehs"]])                 # [negative; prompt], text only (..._ipa_controlnet.py:550)
+    for t in (981, 481, 1):
+        down, mid = c(lmi, t, pec, d["pose"], 1.0)
+        cond = o(d["x"], t, d["ehs_c"], cross_attention_kwargs={"sa_hidden_states": d["sa"]},
+                 down_block_additional_residuals=[r[1:2] for r in down], mid_block_additional_residual=mid[1:2])
+        unc = o(d["x"], t, d["ehs_u"], down_block_additional_residuals=[r[0:1] for r in down], mid_block_additional_residual=mid[0:1])
+        plain = o(d["x"], t, d["ehs_u"])
+        ipa[f"t{t}"] = dict(out_uncond=unc.clone(), out_cond=cond.clone())
+        print("ipa t", t, "uncond std", unc.std().item(), "controlnet effect rel rms",
+              ((unc - plain).pow(2).mean().sqrt() / plain.pow(2).mean().sqrt()).item())
+    cases["ipa_controlnet"] = ipa
+    torch.save(cases, os.path.join(OUT, "unet_forward_timesteps.pt"))
+    print("unet_forward_timesteps.pt", os.path.getsize(os.path.join(OUT, "unet_forward_timesteps.pt")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     import sys
-    what = sys.argv[1] if len(sys.argv) > 1 else "all"          # base | full | geometry | unet | all
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"          # base | full | geometry | unet | timesteps | all
     if what in ("base", "all"):
         main()
     if what in ("full", "all"):
@@ -358,3 +422,5 @@ if __name__ == "__main__":
         main_geometry()
     if what in ("unet", "all"):
         main_unet()
+    if what in ("timesteps", "all"):
+        main_timesteps()

@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 def test_binding_covers_header(lib):
     from imagdressing_amd import _lib
     assert sorted(_lib.SYMBOLS) == declared_functions()
-    assert lib.imd_abi_version() == 7
+    assert lib.imd_abi_version() == _lib.ABI_VERSION == 8
 
 
 def header_struct_fields(name):
@@ -62,6 +62,45 @@ def test_struct_layout_matches_header(cname, pyname):
     from imagdressing_amd import _lib
     py = [f[0] for f in getattr(_lib, pyname)._fields_]
     assert py == header_struct_fields(cname)
+
+
+def test_integration_md_ctypes_snippet_matches_header():
+    """INTEGRATION.md section 2 shows a maintainer the ctypes mirror of imd_attn_params: the fenced snippet is parsed and its
+    _fields_ must be the header's, name for name, in order (a stale snippet hands the library a truncated struct)."""
+    import ast
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    snippet = [b for b in blocks if "class AttnParams" in b]
+    assert len(snippet) == 1
+    tree = ast.parse(snippet[0])
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "AttnParams"][0]
+    assign = [n for n in cls.body if isinstance(n, ast.Assign) and n.targets[0].id == "_fields_"][0]
+    names = [elt.elts[0].value for elt in assign.value.elts]
+    assert names == header_struct_fields("imd_attn_params")
+    types = [ast.unparse(elt.elts[1]) for elt in assign.value.elts]
+    from imagdressing_amd import _lib
+    mine = [f[1] for f in _lib.AttnParams._fields_]
+    assert [getattr(ctypes, ty.split(".")[-1]) for ty in types] == mine          # (c_uint32 is an alias of c_uint)
+    assert "struct_bytes = C.sizeof(p)" in snippet[0] and "imd_abi_version() == %d" % _lib.ABI_VERSION in snippet[0]
+
+
+def test_foreign_struct_size_is_refused(lib):
+    """ABI v8: a parameter block whose struct_bytes is not the library's sizeof is refused before any field is read (no GPU needed:
+    the check precedes the launch)."""
+    from imagdressing_amd import _lib
+    for cls, fn, extra in ((_lib.AttnParams, lib.imd_attention, (None,)), (_lib.ConvGemmParams, lib.imd_conv_gemm, (0, None)),
+                           (_lib.GroupNormParams, lib.imd_groupnorm, (None,)), (_lib.LayerNormParams, lib.imd_layernorm, (None,)),
+                           (_lib.DdimParams, lib.imd_ddim_cfg_step, (None,)), (_lib.FfParams, lib.imd_ff_geglu, (None,))):
+        p = cls()
+        assert p.struct_bytes == ctypes.sizeof(cls)
+        p.struct_bytes = ctypes.sizeof(cls) - 8                 # what a binding of an older, shorter header would pass
+        assert fn(ctypes.byref(p), *extra) != 0
+        assert b"parameter block is" in lib.imd_last_error() and b"ABI v8" in lib.imd_last_error()
+        p.struct_bytes = 0                                      # a v7 caller: first word is the low half of a pointer or zero
+        assert fn(ctypes.byref(p), *extra) != 0 and b"parameter block is" in lib.imd_last_error()
+    q = _lib.ConvGemmParams()
+    q.struct_bytes = 4
+    assert lib.imd_conv_patch_supported(ctypes.byref(q)) == 0 and lib.imd_gemm_dma_supported(ctypes.byref(q)) == 0
 
 
 def test_pure_queries_work_without_gpu(lib):

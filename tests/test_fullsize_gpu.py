@@ -111,6 +111,43 @@ def test_full_width_unet_forward_vs_oracle(full_oracle, dtype):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# full-width forwards at the ENDS of the schedule and with the configs[2] stack, against the committed fp32-oracle fixture
+# ----------------------------------------------------------------------------------------------------------------
+_TS_INPUTS = {}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_full_width_unet_forward_at_three_timesteps_vs_committed_oracle(dtype):
+    """tests/golden/unet_forward_timesteps.pt (oracle/make_golden.py timesteps): t = 981 (first step of the 50-step schedule,
+    eps ~ z), 481, 1 (last step), for (a) the configs[1] processors and (b) the configs[2] stack -- LoraRefS + LoRAIP (rank 128,
+    77 + 4 tokens) with the residuals of the engine's own pose ControlNet -- CFG layout, full width, 64x64 latent.
+    Bars: fp16 the north-star atol 1e-2 on every element of eps at every timestep; bf16 rms 2.5 % / worst element 0.12 x std
+    (8 mantissa bits)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import os
+    from tests.unet_fixture import GOLDEN, ipa_controlnet_forward_inputs, measure_unet_parity_timesteps, unet_forward_inputs
+    if "base" not in _TS_INPUTS:
+        full = torch.load(os.path.join(GOLDEN, "unet_forward_full.pt"), weights_only=False)["latent_64x64"]
+        gold = torch.load(os.path.join(GOLDEN, "unet_forward_timesteps.pt"), weights_only=False)
+        _TS_INPUTS["base"] = unet_forward_inputs(64, 64, full)
+        _TS_INPUTS["ipa"] = ipa_controlnet_forward_inputs(gold["ipa_controlnet"], base=_TS_INPUTS["base"])
+    res = measure_unet_parity_timesteps(torch.device("cuda"), dtype, inputs=_TS_INPUTS["base"], ipa_inputs=_TS_INPUTS["ipa"])
+    for case in ("refs", "ipa_controlnet"):
+        for t in (981, 481, 1):
+            for half in ("cond", "uncond"):
+                st = res[case][f"t{t}"][half]
+                assert res[case][f"t{t}"]["finite"]
+                if dtype == torch.float16:
+                    assert st["max_abs"] <= 1e-2 and st["rel_rms"] < 5e-3, (case, t, half, st)
+                else:
+                    assert st["rel_rms"] < 2.5e-2 and st["max_abs"] < 0.12 * st["ref_std"], (case, t, half, st)
+    if dtype == torch.float16:
+        assert res["refs"]["meets_atol_1e-2"] and res["ipa_controlnet"]["meets_atol_1e-2"]
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # BASELINE configs[2] at FULL width: IP-Adapter FaceID-Plus tokens + rank-128 LoRA on every attention + pose ControlNet
 # ----------------------------------------------------------------------------------------------------------------
 _IPA_ORACLE = {}

@@ -120,3 +120,22 @@ def test_proj_plus_restatement(golden_resampler):
     sd, idv, clip = proj_plus_inputs(c)
     _close(R.proj_plus_forward(sd, idv, clip), c["out"], 5e-5)
     _close(R.proj_plus_forward(sd, idv, clip, shortcut=True, scale=0.7), c["out_shortcut"], 5e-5)
+
+
+def test_unet_timestep_fixture_is_complete():
+    """tests/golden/unet_forward_timesteps.pt (oracle/make_golden.py timesteps): both processor stacks, every timestep, finite, the two
+    CFG halves differ (garment / ControlNet residual halves are really split), and the timesteps differ from each other."""
+    import os
+    g = torch.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unet_forward_timesteps.pt"), weights_only=False)
+    assert set(g) == {"refs", "ipa_controlnet"}
+    for case, ts in (("refs", (981, 1)), ("ipa_controlnet", (981, 481, 1))):
+        outs = []
+        for t in ts:
+            e = g[case][f"t{t}"]
+            for k in ("out_cond", "out_uncond"):
+                assert e[k].shape == (1, 4, 64, 64) and torch.isfinite(e[k]).all()
+            assert (e["out_cond"] - e["out_uncond"]).abs().max() > 0.05
+            outs.append(e["out_cond"])
+        for a, b in zip(outs, outs[1:]):
+            assert (a - b).abs().max() > 0.05
+    assert {"ctrl", "lora0", "ip0", "ehs_c", "pose"} <= set(g["ipa_controlnet"]["digests"])

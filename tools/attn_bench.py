@@ -1,6 +1,6 @@
 """Micro-benchmark of the fused hybrid-attention kernel at the UNet level-0 shape of the 512x512 CFG batch
 (4 cond rows with the garment branch + 4 uncond rows, N = M = 4096, 8 heads, d = 40) and the other levels.
-Also the target of the PMC passes in tools/pmc_attn.sh (HBM traffic, MFMA busy cycles)."""
+Also the target of the PMC passes in tools/gpu.sh pmc (HBM traffic, MFMA busy cycles)."""
 import argparse, json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

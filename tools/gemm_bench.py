@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--filter", default="")
     ap.add_argument("--dtype", default="bf16")
-    ap.add_argument("--flags", default="3", help="comma list of GEMM tuning flag values to A/B (knob 2)")
+    ap.add_argument("--flags", default="23", help="comma list of GEMM tuning flag values to A/B (knob 2)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     cfgs = [int(c) for c in a.cfgs.split(",")]

@@ -1,0 +1,65 @@
+#!/bin/bash
+# ONE parameterised lease script for the GPU box (replaces the per-experiment tools/run_r2*.sh / run_r3*.sh of earlier rounds).
+# Run from the repo root on the GPU box, e.g.   gpurun --timeout 900 -- 'bash tools/gpu.sh tests; bash tools/gpu.sh bench r4a'
+#
+#   tests  [pytest args]           GPU parity suite (tail of the output -> gpurun_out/<tag>_pytest.txt; TAG env, default "t")
+#   smoke                          __graft_entry__.smoke()
+#   bench  TAG [bench args]        full default bench line -> gpurun_out/TAG_bench.json
+#   quick  TAG [bench args]        bench without the diagnostics legs (headline timing only), 3 steps
+#   trace  TAG [bench args]        rocprofv3 --kernel-trace --stats of the quick bench -> gpurun_out/TAG_kernel_trace_summary.md
+#   ab-env TAG VAR V1 V2 [args]    same-box A/B of one environment variable, interleaved twice (quick bench)
+#   ab-lib TAG L1 L2 ...           same-box A/B of library builds imagdressing_amd/libimagdressing_hip_<L>.so ("cur" = shipped)
+#   pmc    OUT PATTERN cmd...      PMC counters of the kernels matching PATTERN in cmd (separate passes, --kernel-trace only)
+#   run    TAG cmd...              any command, stdout+stderr -> gpurun_out/TAG.txt (tail printed)
+R="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$R"; mkdir -p gpurun_out
+QUICK="--no-secondary --no-geometry-secondary --no-parity --no-latency --no-flops --no-live-traffic --no-cpu-baseline --no-power --no-configs"
+line() { python -c "import sys,json; d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1]); r=d.get('roofline') or {}; print('$1', d['ms_per_step'], d['value'], r.get('achieved'))"; }
+task="$1"; shift
+case "$task" in
+  tests)
+    (timeout 1500 python -m pytest tests -q -m gpu "$@" 2>&1 | tail -8) | tee gpurun_out/${TAG:-t}_pytest.txt ;;
+  smoke)
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ;;
+  bench)
+    tag="$1"; shift
+    timeout 900 python bench.py "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 6000 gpurun_out/${tag}_bench.json ;;
+  quick)
+    tag="$1"; shift
+    timeout 400 python bench.py --steps 3 --warmup 1 $QUICK "$@" 2> gpurun_out/${tag}_quick.err | tee gpurun_out/${tag}_quick.json | line "$tag $*" ;;
+  trace)
+    tag="$1"; shift
+    mkdir -p gpurun_out/$tag
+    (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag -o trace -- python $R/bench.py --steps 2 --warmup 1 $QUICK "$@" \
+        > $R/gpurun_out/${tag}_bench_under_rocprof.json 2> $R/gpurun_out/${tag}_rocprof.err)
+    DB=$(find gpurun_out/$tag -name "*.db" | head -1)
+    python tools/rocprof_summary.py $DB gpurun_out/${tag}_kernel_trace_summary.md
+    head -34 gpurun_out/${tag}_kernel_trace_summary.md
+    find gpurun_out/$tag -name "*.db" -size +20000k -delete ;;
+  ab-env)
+    tag="$1"; var="$2"; v1="$3"; v2="$4"; shift 4
+    for v in $v1 $v2 $v1 $v2; do
+      env $var=$v timeout 400 python bench.py --steps 3 --warmup 1 $QUICK "$@" 2>/dev/null | line "$var=$v"
+    done | tee gpurun_out/${tag}_ab.txt ;;
+  ab-lib)
+    tag="$1"; shift
+    for rep in 1 2; do for lib in "$@"; do
+      if [ $lib = cur ]; then unset IMD_LIB_PATH; else export IMD_LIB_PATH=$R/imagdressing_amd/libimagdressing_hip_$lib.so; fi
+      timeout 400 python bench.py --steps 3 --warmup 1 $QUICK 2>/dev/null | line "lib=$lib"
+    done; done | tee gpurun_out/${tag}_ab.txt ;;
+  pmc)
+    OUT="$1"; PAT="$2"; shift 2
+    mkdir -p $R/$OUT; i=0
+    for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
+               "GRBM_GUI_ACTIVE GRBM_COUNT" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS" \
+               "TCC_HIT_sum TCC_MISS_sum"; do
+      i=$((i+1))
+      (cd /tmp && export TMPDIR=/tmp && cd $R && timeout 150 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pass$i -o a -- "$@" > $R/$OUT/pass$i.out 2>&1)
+    done
+    python tools/pmc_summary.py $OUT "$PAT" > $OUT/summary.txt 2>&1; cat $OUT/summary.txt
+    find $OUT -name "*.csv" -size +2000k -delete ;;
+  run)
+    tag="$1"; shift
+    ("$@" 2>&1 | tail -60) | tee gpurun_out/${tag}.txt ;;
+  *) echo "tools/gpu.sh: unknown task '$task'" >&2; exit 2 ;;
+esac

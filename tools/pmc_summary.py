@@ -1,4 +1,4 @@
-"""Average the PMC counters of the conv_gemm dispatches found under a tools/pmc_gemm.sh output directory."""
+"""Average the PMC counters of the conv_gemm dispatches found under a tools/gpu.sh pmc output directory."""
 import csv, glob, sys, collections
 root = sys.argv[1]
 pat = sys.argv[2] if len(sys.argv) > 2 else "conv_gemm_kernel"
