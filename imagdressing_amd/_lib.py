@@ -106,6 +106,7 @@ SYMBOLS = {
     "imd_attention_fp8": (C.c_int, [C.POINTER(AttnParams), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "imd_attn_quantize_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "imd_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "imd_get_tuning": (C.c_int, [C.c_int]),
     "imd_attn_padded_dims": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "imd_groupnorm": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p]),
     "imd_groupnorm_coeffs": (C.c_int, [C.POINTER(GroupNormParams), C.c_void_p, C.c_void_p, C.c_void_p]),

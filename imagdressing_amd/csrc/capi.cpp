@@ -106,6 +106,8 @@ int imd_set_tuning(int knob, int value) {
     }
 }
 
+int imd_get_tuning(int knob) { return knob == 0 ? g_attn_qw40 : knob == 1 ? g_attn_xcd : knob == 2 ? g_gemm_flags : -1; }
+
 int imd_attn_padded_dims(int D, int* dpk, int* dpv) {
     IMD_REQUIRE(D == 40 || D == 64 || D == 80 || D == 160, "attn_padded_dims: unsupported head dim %d", D);
     if (dpk) *dpk = imd_attn_dpk(D);

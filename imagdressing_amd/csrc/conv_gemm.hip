@@ -436,6 +436,12 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         p.flags |= g_gemm_flags & 16;
     }
     if (p.split_k <= 1) p.splitk_counters = nullptr;
+    // GroupNorm statistics of the output (ABI v6+): only the halo-patch kernel's un-split epilogue produces them; every other request is an
+    // ERROR -- a launch that silently skipped the write would leave the next imd_groupnorm(nparts > 0) reading uninitialised memory, and
+    // gn_stats_groups = 0 / fewer than 8 channels per group would divide by zero / straddle more than two groups in the kernel
+    if (p.gn_stats_out != nullptr && (cfg != 5 || imd_conv_patch_stats_parts_of(p) == 0))
+        return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 without K slices, a row-major 16-bit output and 1 <= groups <= 64 with N %% groups == 0 "
+                             "and N / groups >= 8 (got cfg=%d split_k=%d groups=%d N=%d); ask imd_conv_patch_stats_parts() first", cfg, p.split_k, p.gn_stats_groups, p.N);
     if (p.splitk_counters != nullptr) {          // one counter per output tile; larger grids keep the two-launch path
         int bm = 128, bn = 128;
         if (cfg == 5) { bm = 128; bn = 128; } else tile_dims(cfg, &bm, &bn);

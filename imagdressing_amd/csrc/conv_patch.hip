@@ -401,8 +401,11 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         if (e < nv) {
-                            if (e < st_split) { st[0] += v[e]; st[1] += v[e] * v[e]; }
-                            else { st[2] += v[e]; st[3] += v[e] * v[e]; }
+                            // statistics of the STORED tensor (the value after rounding to 16 bits): what the standalone gn_stats_kernel and the
+                            // reference's GroupNorm see, so the result does not depend on which kernel produced the tensor
+                            const float r = E::tof(E::fromf(v[e]));
+                            if (e < st_split) { st[0] += r; st[1] += r * r; }
+                            else { st[2] += r; st[3] += r * r; }
                         }
                     }
                 }

@@ -115,11 +115,23 @@ def garment_features_broadcast(pipe, ref_latents: torch.Tensor, cloth_tokens: to
             flat[total] = 0.0
         except Exception as e:       # noqa: BLE001  (re-raised below, after the other ranks have been released)
             err = e
-            flat.zero_()
-            flat[total] = 1.0
-    broadcast_packed(flat, 0)
-    if err is not None:
-        raise err
+            try:                     # a device-side fault makes these two launches raise as well: the status then travels in a FRESH
+                flat.zero_()         # host-built buffer (below) -- rank 0 must reach the broadcast whatever happened, or the others hang
+                flat[total] = 1.0
+            except Exception:        # noqa: BLE001
+                flat = None
+    if err is not None and flat is None:
+        try:
+            host = torch.zeros(total + 1, dtype=runet.dtype)
+            host[total] = 1.0
+            flat = host.to(pipe.device)
+        except Exception:            # noqa: BLE001  (the device is gone: nothing can be sent; the process group's own timeout releases the others)
+            raise err
+    try:
+        broadcast_packed(flat, 0)
+    finally:
+        if err is not None:
+            raise err
     if rank() != 0 and float(flat[total].item()) != 0.0:
         raise RuntimeError("rank 0 failed while computing the garment features (status flag of the packed broadcast); see its traceback")
     flat = flat[:total]

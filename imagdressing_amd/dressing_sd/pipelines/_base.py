@@ -98,7 +98,25 @@ class PipelineBase:
         per step instead of ~500 kernel launches.  Worth it where the loop is host-bound (small batches); ignored for UniPC, step
         callbacks, traces and per-step ControlNet gating."""
         self._step_graph = bool(flag)
+        if not flag:
+            self.release_step_graph()
         return self
+
+    def release_step_graph(self):
+        """Drop the captured step graph, the side stream it was recorded on and every scratch buffer keyed by that stream
+        (``ops.clear_workspaces(stream=...)``): the graph pins a private memory pool, and the per-stream workspaces (attention operand
+        buffers, GroupNorm partials, a >= 16 MB split-K slab) would otherwise live as long as the process."""
+        side = self.__dict__.pop("_graph_stream", None)
+        self.__dict__.pop("_last_step_graph", None)
+        if side is not None:
+            side.synchronize()
+            ops.clear_workspaces(stream=side.cuda_stream)
+
+    def __del__(self):
+        try:
+            self.release_step_graph()
+        except Exception:        # noqa: BLE001  (interpreter shutdown)
+            pass
 
     def enable_vae_slicing(self):
         self.vae.enable_slicing()

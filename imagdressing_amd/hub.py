@@ -83,7 +83,8 @@ class PendingModel:
             self.__dict__["_dtype"] = dtype
         if device is None:
             return self
-        return self._build(device)
+        eng = self.__dict__.get("_engine")              # (already built by a first use: same engine, `.to(device)` is then a no-op check)
+        return eng.to(device=device) if eng is not None else self._build(device)
 
     def _build(self, device="cuda"):
         dtype = self.__dict__.get("_dtype") or torch.float16      # the reference's dtype (inference_IMAGdressing.py:42-52)
@@ -92,8 +93,20 @@ class PendingModel:
         return eng
 
     def __getattr__(self, name):
-        raise AttributeError(f"{self._cls.__name__}.from_pretrained(...) handle has no attribute {name!r}: call "
-                             ".to(dtype=..., device=...) first (that is where the MI355X engine is built)")
+        """First use of the engine surface (``set_attn_processor``, ``load_state_dict``, ``attn_processors``, a call ...) on a handle that
+        has its element type but never got a device: the engine is built NOW on the current HIP device ("on first use", as ``to``'s
+        docstring says) and the handle forwards to it from then on.  Without any ``.to`` / ``torch_dtype`` the handle stays inert."""
+        if name.startswith("__") or "_dtype" not in self.__dict__:
+            raise AttributeError(f"{self._cls.__name__}.from_pretrained(...) handle has no attribute {name!r}: call "
+                                 ".to(dtype=..., device=...) first (that is where the MI355X engine is built)")
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            eng = self.__dict__["_engine"] = self._build("cuda")
+        return getattr(eng, name)
+
+    def __call__(self, *args, **kw):
+        self.__getattr__("dtype")                       # builds on first use (or raises the "call .to(...) first" error)
+        return self.__dict__["_engine"](*args, **kw)
 
 
 class PretrainedMixin:

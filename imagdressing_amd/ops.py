@@ -91,14 +91,22 @@ def k_buffer(shape: Sequence[int], D: int, dtype, device, tag: Optional[str] = N
     return t
 
 
-def clear_workspaces():
-    """Drop every persistent scratch buffer (attention operand buffers, GroupNorm partials, split-K slabs, cached fp8 K / V)."""
-    _ws.clear()
-    _splitk_ws.clear()
-    _splitk_cnt.clear()
-    _proj_cnt.clear()
-    for fn in _clear_hooks:
-        fn()
+def clear_workspaces(stream: Optional[int] = None):
+    """Drop every persistent scratch buffer (attention operand buffers, GroupNorm partials, split-K slabs, cached fp8 K / V).
+    ``stream`` (a raw stream handle, ``torch.cuda.Stream.cuda_stream``): only the buffers keyed by THAT stream -- what a pipeline calls
+    when it releases its side stream / captured step graph, so that a later stream that happens to reuse the handle value cannot pick up
+    a buffer the caching allocator still associates with the old stream, and nothing accumulates per stream for the process lifetime."""
+    if stream is None:
+        _ws.clear()
+        _splitk_ws.clear()
+        _splitk_cnt.clear()
+        _proj_cnt.clear()
+        for fn in _clear_hooks:
+            fn()
+        return
+    for table in (_ws, _splitk_ws, _splitk_cnt, _proj_cnt):
+        for key in [k for k in table if k[-1] == stream]:
+            del table[key]
 
 
 _clear_hooks = []          # modules holding device-side caches of their own register a clearer here (adapter/attention_processor.py)

@@ -241,6 +241,8 @@ int imd_attn_padded_dims(int D, int* dpk, int* dpv);
  * bit2: XCD-aware tile order -- each XCD's L2 owns whole row tiles or whole channel tiles, whichever moves fewer bytes;
  * bit4: row tiles visited in groups of 8 inside an XCD's range). */
 int imd_set_tuning(int knob, int value);
+/* current value of a knob (-1: unknown knob): lets a harness snapshot and restore the process-global settings around an A/B */
+int imd_get_tuning(int knob);
 
 /* GroupNorm (+SiLU) over NHWC: diffusers ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out. */
 int imd_groupnorm(const imd_groupnorm_params* p, void* stream);

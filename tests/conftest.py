@@ -45,3 +45,24 @@ def golden_geometry():
     (oracle/make_golden.py::main_geometry)."""
     import torch
     return torch.load(os.path.join(GOLDEN, "processors_default_geometry.pt"), weights_only=False)
+
+
+_KNOB_NAMES = ("PATCH_CONV", "SPLITK_IN_KERNEL", "FUSED_FF", "FUSED_GN_STATS", "CFG_PAIR_DEDUP", "FUSED_LN", "FUSED_OUT_PROJ", "ATTN_FP8")
+
+
+@pytest.fixture(autouse=True)
+def _restore_tuning_knobs():
+    """The library's tuning knobs (imd_set_tuning) and the ops-level switches are PROCESS-GLOBAL: a test that flips one and fails (or
+    forgets) would silently change every later test.  Snapshot before, restore after -- every test starts from the shipped settings."""
+    from imagdressing_amd import _lib, ops
+    py = {k: getattr(ops, k) for k in _KNOB_NAMES if hasattr(ops, k)}
+    lib = _lib._lib                      # only if some earlier test already loaded it (never force a load here)
+    native = None if lib is None else [lib.imd_get_tuning(k) for k in range(3)]
+    yield
+    for k, v in py.items():
+        setattr(ops, k, v)
+    lib = _lib._lib
+    if lib is not None and native is not None:
+        for k, v in enumerate(native):
+            if lib.imd_get_tuning(k) != v:
+                lib.imd_set_tuning(k, v)

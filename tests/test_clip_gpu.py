@@ -174,3 +174,105 @@ def test_pipeline_with_hip_clip_encoders(hf):
     b = pipe(prompt=None, null_prompt=None, negative_prompt=None, prompt_embeds=pe, negative_prompt_embeds=ne,
              ref_clip_hidden_states=hid, **common).images
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@torch.no_grad()
+def test_main_call_sequence_of_the_reference_script(hf):
+    """The ``__main__`` body of /root/reference/inference_IMAGdressing.py:148-189, statement for statement, on the small config: PIL
+    garment -> ``resize_img`` (:25-37) -> the torchvision transform (:158-162, restated with PIL + torch: torchvision is not in this
+    image) -> ``CLIPImageProcessor`` pixel values (:171; the real transformers class) -> ``pipe(prompt=..., null_prompt=...,
+    negative_prompt=..., ref_image=vae_clothes, ref_clip_image=..., width, height, num_images_per_prompt, guidance_scale,
+    image_scale, generator, num_inference_steps)`` (:175-187) with NO embeddings / latents injected -> ``.images`` is a list of PIL
+    images of the requested size (:189-193 pastes them into a grid).  VAE encode of the garment, CLIP encoders, resampler, garment
+    UNet, denoising loop and VAE decode all run on the HIP engines.  Deterministic for a seeded CPU generator."""
+    import numpy as np
+    from PIL import Image
+    from transformers import CLIPImageProcessor
+    from imagdressing_amd.adapter.resampler import Resampler
+    from imagdressing_amd.clip import CLIPTextModel, CLIPVisionModelWithProjection
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+    from imagdressing_amd.scheduler import DDIMScheduler
+    from imagdressing_amd.vae import AutoencoderKL
+    from oracle import vae as OV
+    from tests.harness import SMALL, build_pair
+    dt = torch.float16
+    p = build_pair(SMALL, seed=0, dtype=dt)
+    tcfg = dict(TEXT_SMALL, hidden_size=64, num_attention_heads=1, intermediate_size=128)
+    text = CLIPTextModel(seeded(hf.CLIPTextModel(hf.CLIPTextConfig(**tcfg)), 8).state_dict(), tcfg, "cuda", dt)
+    vis = CLIPVisionModelWithProjection(seeded(hf.CLIPVisionModelWithProjection(hf.CLIPVisionConfig(**VIS_SMALL)), 9).state_dict(),
+                                        VIS_SMALL, "cuda", dt)
+    vcfg = dict(block_out_channels=(64, 128, 128, 128), norm_num_groups=8)
+    vae = AutoencoderKL(OV.seeded_state_dict(vcfg, seed=0), vcfg, "cuda", dt)
+    torch.manual_seed(3)
+    proj = Resampler(dim=64, depth=2, dim_head=64, heads=2, num_queries=16, embedding_dim=160, output_dim=64, ff_mult=2).to(device="cuda", dtype=dt)
+
+    class Tok:                                    # (no vocabulary files offline) the CLIPTokenizer surface the pipeline touches
+        model_max_length = 77
+
+        def __call__(self, text, padding=None, max_length=77, truncation=True, return_tensors="pt"):
+            import types
+            text = [text] if isinstance(text, str) else text
+            ids = torch.full((len(text), max_length), 999, dtype=torch.int64)
+            for i, s in enumerate(text):
+                toks = [1 + (ord(c) % 900) for c in s][:max_length - 1]
+                ids[i, :len(toks)] = torch.tensor(toks, dtype=torch.int64)
+            return types.SimpleNamespace(input_ids=ids)
+    noise_scheduler = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                    clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    pipe = IMAGDressing_v1(unet=p["e_unet"], reference_unet=p["e_ref"], vae=vae, tokenizer=Tok(), text_encoder=text, image_encoder=vis,
+                           ImgProj=proj, scheduler=noise_scheduler, safety_checker=None, feature_extractor=CLIPImageProcessor)
+
+    def resize_img(input_image, max_side=160, min_side=128, mode=Image.BILINEAR, base_pixel_number=64):      # :25-37 (sizes / 4 for the small config)
+        w, h = input_image.size
+        ratio = min_side / min(h, w)
+        w, h = round(ratio * w), round(ratio * h)
+        ratio = max_side / max(h, w)
+        input_image = input_image.resize([round(ratio * w), round(ratio * h)], mode)
+        w_resize_new = (round(ratio * w) // base_pixel_number) * base_pixel_number
+        h_resize_new = (round(ratio * h) // base_pixel_number) * base_pixel_number
+        return input_image.resize([w_resize_new, h_resize_new], mode)
+
+    def img_transform(img):                       # transforms.Compose([Resize([H, W], BILINEAR), ToTensor(), Normalize([0.5], [0.5])]) (:158-162)
+        img = img.resize((128, 160), Image.BILINEAR)
+        x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
+        return (x - 0.5) / 0.5
+
+    # ================= body of __main__, inference_IMAGdressing.py:148-189 =================
+    num_samples = 1
+    clip_image_processor = CLIPImageProcessor(size={"shortest_edge": 56}, crop_size={"height": 56, "width": 56})      # (the small vision tower's input size)
+    prompt = 'A beautiful woman, best quality, high quality'
+    null_prompt = ''
+    negative_prompt = 'bare, naked, nude, undressed, monochrome, lowres, bad anatomy, worst quality, low quality'
+    rng = np.random.RandomState(0)
+    clothes_img = Image.fromarray(rng.randint(0, 255, (300, 240, 3), dtype=np.uint8)).convert("RGB")      # Image.open(args.cloth_path).convert("RGB")
+    clothes_img = resize_img(clothes_img)
+    vae_clothes = img_transform(clothes_img).unsqueeze(0)
+    ref_clip_image = clip_image_processor(images=clothes_img, return_tensors="pt").pixel_values
+
+    def run():
+        generator = torch.Generator(device="cpu").manual_seed(42)
+        return pipe(
+            ref_image=vae_clothes,
+            prompt=prompt,
+            ref_clip_image=ref_clip_image,
+            null_prompt=null_prompt,
+            negative_prompt=negative_prompt,
+            width=128,
+            height=160,
+            num_images_per_prompt=num_samples,
+            guidance_scale=7.5,
+            image_scale=1.0,
+            generator=generator,
+            num_inference_steps=6,
+        ).images
+    output = run()
+    # ================= end =================
+    assert isinstance(output, list) and len(output) == num_samples and isinstance(output[0], Image.Image)
+    assert output[0].size == (128, 160) and output[0].mode == "RGB"
+    save_output = [clothes_img.resize((128, 160), Image.BICUBIC), output[0]]          # :190-193 (image_grid pastes them side by side)
+    grid = Image.new("RGB", size=(2 * 128, 160))
+    for i, img in enumerate(save_output):
+        grid.paste(img, box=(i * 128, 0))
+    arr = np.asarray(output[0])
+    assert arr.std() > 1.0                        # not a constant image
+    assert np.array_equal(arr, np.asarray(run()[0]))      # same seed -> same picture (no atomics, fixed-order reductions)

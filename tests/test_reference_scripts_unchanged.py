@@ -51,6 +51,7 @@ def model_root(tmp_path, monkeypatch):
     _write_hf_dir(tmp_path / "stabilityai" / "sd-vae-ft-mse", OV.seeded_state_dict(vcfg, seed=0), vcfg)
     sd_c = E.random_state_dict(E.controlnet_param_shapes(full), 2, zero_convs=True)
     _write_hf_dir(tmp_path / "lllyasviel" / "control_v11p_sd15_openpose", sd_c, {k: full[k] for k in keys})
+    _write_hf_dir(tmp_path / "lllyasviel" / "control_v11p_sd15_inpaint", sd_c, {k: full[k] for k in keys})       # ..._controlnetinpainting.py:148
     torch.manual_seed(0)
     tcfg = CLIPTextConfig(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2,
                           max_position_embeddings=77, hidden_act="quick_gelu", projection_dim=64)
@@ -102,10 +103,13 @@ def _exec_script_defs(script, monkeypatch):
     for m in [k for k in sys.modules if k == "diffusers" or k.startswith("diffusers.")]:
         monkeypatch.delitem(sys.modules, m)
     # host-side dependencies of the scripts that are outside the hot path and absent from this image: import-only stubs
-    for name in ("torchvision", "torchvision.transforms", "cv2", "insightface", "insightface.app", "insightface.utils"):
+    for name in ("torchvision", "torchvision.transforms", "cv2", "insightface", "insightface.app", "insightface.utils", "onnxruntime",
+                 # the inpainting script's mask / pose preprocessing (SCHP human parsing, OpenPose: out of scope)
+                 "preprocess", "preprocess.humanparsing", "preprocess.humanparsing.run_parsing", "preprocess.openpose",
+                 "preprocess.openpose.run_openpose", "preprocess.utils_mask"):
         if name not in sys.modules:
             mod = types.ModuleType(name)
-            mod.__dict__.update(transforms=None, FaceAnalysis=object, face_align=None)
+            mod.__dict__.update(transforms=None, FaceAnalysis=object, face_align=None, Parsing=object, OpenPose=object, get_mask_location=None)
             monkeypatch.setitem(sys.modules, name, mod)
     import transformers
 
@@ -134,6 +138,7 @@ def _exec_script_defs(script, monkeypatch):
     ("inference_IMAGdressing_cartoon_style.py", "IMAGDressing_v1_pipeline"),
     ("inference_IMAGdressing_controlnetpose.py", "IMAGDressing_v1_pipeline_controlnet"),
     ("inference_IMAGdressing_ipa_controlnetpose.py", "IMAGDressing_v1_pipeline_ipa_controlnet"),
+    ("inference_IMAGdressing_controlnetinpainting.py", "IMAGDressing_v1_pipeline_controlnet_inpainting"),      # the configs[4] surface
 ])
 def test_reference_script_prepare_runs_unchanged(script, pipeline_mod, model_root, monkeypatch, tmp_path):
     root, full, sd_u = model_root
