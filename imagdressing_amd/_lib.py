@@ -113,6 +113,7 @@ SYMBOLS = {
     "imd_conv_patch_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_conv_patch2_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_conv_patch_stats_parts": (C.c_int, [C.POINTER(ConvGemmParams)]),
+    "imd_conv_gemm_stats_parts": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int]),
     "imd_gemm_dma_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_row_linear": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int, C.c_float, C.c_void_p]),
     "imd_row_linear_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),

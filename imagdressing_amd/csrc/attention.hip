@@ -453,7 +453,7 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 //   2: 2 query blocks per wave, 32-key softmax blocks, speculative exp (round-1 default)
 //   4: 1 query block per wave, 32-key blocks, speculative exp      3: 1 query block, 64-key blocks, exact max every block
 //   1: as 3 with speculative exp
-int g_attn_qw40 = 10;
+int g_attn_qw40 = 12;
 
 int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }

@@ -220,6 +220,13 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
     constexpr bool DMA = (VAR & 128) != 0;
     constexpr bool TAIL = (VAR & 8192) != 0;
     constexpr bool PROJ = (VAR & 1048576) != 0;            // out-projection fused: O tiles stored write-through, last head of a row block projects
+    // STAT (VAR & 2097152, round 4): the main loop unrolled over the three ring slots, so that every LDS address of an iteration -- fragment
+    // reads AND the LDS-DMA destinations -- is a compile-time offset; the staging sequence of a piece shrinks from ~15 instructions (ring
+    // arithmetic, out-of-range selects compiled to branches, M0 save / restore, five wait states) to three (s_add m0 / s_nop / buffer_load)
+    // plus one running-offset add.  The issue-mix probe (tools/probes/issue_mix_probe.hip) puts this kernel's step within 15 % of what its
+    // MFMA + VALU + LDS + DMA mix costs in isolation; what is left above that is scalar / address bookkeeping like this.
+    constexpr bool STAT = (VAR & 2097152) != 0;
+    static_assert(!STAT || ((VAR & 128) && (VAR & 8192) && !(VAR & 32768)), "the static-ring loop exists for the 4-wave LDS-DMA kernel with the 16x16x32 tail");
     static_assert(!PROJ || (TAIL && !(VAR & 32768)), "the fused out-projection lives in the 4-wave kernel with the 16x16x32 tail");
     constexpr int NW = (VAR & 32768) ? 8 : 4;              // waves per workgroup
     constexpr int NT = NW * 64;
@@ -378,6 +385,42 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
                 dneg[i] = ch < 4;                                // unit 0: columns ch * 8 - 32 .. < 0
             }
         }
+        // STAT: per-piece loop state.  Wave 3's third piece (index 11: there are only 11 pieces) re-fetches piece 10 -- the same bytes to the
+        // same place, a benign duplicate -- so that every wave issues three REAL pieces and nothing in the loop depends on the wave.
+        v4i_t sdsc[NPIECE];          // descriptor of the piece (K or V^T)
+        uint32_t sdst[NPIECE];       // LDS byte address of the piece inside ring slot 0
+        uint32_t scur[NPIECE];       // source byte offset of the piece for the NEXT unit to stage (running; += sstr per unit)
+        uint32_t sstr[NPIECE];
+        if constexpr (STAT) {
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) {
+                const int qi = min(wv + NW * i, 10);
+                const bool isk = qi < 6;
+                int src;
+                if (isk) {
+                    const int sl = 64 * qi + lane, r = sl / 6, cs = sl % 6, c = (cs + 6 - 3 * ((r >> 3) & 1)) % 6;
+                    src = (32 + r) * (DPK * 2) + c * 16;
+                } else {
+                    const int sl = 64 * (qi - 6) + lane, dd = sl >> 3, rt = dd - 32;
+                    const int sw = (dd >= 32) ? (((rt >> 1) & 7) ^ ((rt >= 4 && rt < 12) ? 2 : 0)) : ((dd >> 1) & 7);
+                    src = (dd * LP + ((sl & 7) ^ sw) * 8 - 32) * 2;
+                }
+                sstr[i] = isk ? (uint32_t)(KT * DPK * 2) : (uint32_t)(KT * 2);
+                scur[i] = (uint32_t)src + 2u * sstr[i];                      // the loop's first staged unit is unit 2
+                sdst[i] = smem_base + (uint32_t)(isk ? VBYTES_D + 1024 * qi : 1024 * (qi - 6));
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) sdsc[i][c4] = isk ? ds_k[c4] : ds_v[c4];
+            }
+        }
+        auto dma_static = [&](auto slot_c) __attribute__((always_inline)) {      // stage the next unit into ring slot `slot_c` (compile-time)
+            constexpr int SLOT = decltype(slot_c)::value;
+#pragma unroll
+            for (int i = 0; i < NPIECE; ++i) {
+                asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                             : : "v"(scur[i]), "s"(sdst[i]), "s"(sdsc[i]), "n"(SLOT * BUF_D) : "memory");
+                scur[i] += sstr[i];
+            }
+        };
         auto dma_unit = [&](int u, int bufi) {     // u >= 1 inside the loop: no range logic at all (rows / columns past the end read 0)
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {      // EVERY wave issues exactly NPIECE pieces (the counted vmcnt relies on it)
@@ -411,7 +454,7 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
         constexpr int NFR = TAIL ? PD + 1 : 3;
         uint4 fr[NFR];               // LDS fragment ring: fragment f of a step lives in fr[(R0 + f) % 3]  (TAIL: (R0T + f) % (PD + 1))
         auto step = [&](const char* Vs, auto second_c, int j, f32x16 (&sc)[2], f32x16 (&sn)[2], uint4 (&pc)[2][2],
-                        uint4 (&pp)[2][2]) {
+                        uint4 (&pp)[2][2]) __attribute__((always_inline)) {
             constexpr bool SECOND = decltype(second_c)::value;        // second step of a unit: K block kb = 1, V^T groups 2, 3
             constexpr int KB = SECOND ? 1 : 0, G0 = SECOND ? 2 : 0, R0 = SECOND ? 1 : 0;
             const char* Ks = Vs + VBY;
@@ -534,8 +577,11 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
             // (its results are dead on the exact path) and the MFMAs above lose the VALU work they are meant to hide
             asm volatile("" : "+v"(mm));
             const uint32_t top = max(mm & 0xffffu, mm >> 16);
-            const bool forced = (j == 0) || (j * 32 + 32 > L);
-            if (__builtin_expect(forced || __any(top > (uint32_t)E::fromf(__builtin_exp2f(OFFS_THR))), 0)) {
+            // first block (j == 0) or ragged / past-the-end block (j >= L / 32): ONE unsigned compare, folded into the overflow test's
+            // threshold so that the hot path has a single branch per step (forced: every lane passes `top >= 0`)
+            const bool forced = (uint32_t)(j - 1) >= (uint32_t)((L >> 5) - 1);
+            const uint32_t thr1 = forced ? 0u : (uint32_t)E::fromf(__builtin_exp2f(OFFS_THR)) + 1u;
+            if (__builtin_expect(__any(top >= thr1), 0)) {
                 // ---- exact path (first block, ragged / past-the-end block, or a score ran past the deferred maximum): the
                 // block's scores are recomputed from K in global memory (L2), with the pad slot as it stands ----
                 const int krow = j * 32 + swap23(col);
@@ -627,13 +673,33 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
         // P.V of block J - 1 ("drain"): handled after the loop so that the loop body has no per-step range logic
         // (register staging keeps the simpler form: NU full iterations, past-the-end blocks masked to P = 0 on the exact path)
         const int NUF = DMA ? (J >> 1) : NU;
-        auto iteration_sync = [&]() {
+        auto iteration_sync = [&]() __attribute__((always_inline)) {
             if (DMA) { if (NPIECE == 3) dma_wait_keep3(); else dma_wait_keep2(); }   // this wave's pieces of unit u + 1 have landed (u + 2 stays in flight) ...
             if (!(VAR & 8)) __syncthreads();                        // ... and so have everybody else's
         };
         int ring = 0;                                               // u % NRING
         unsigned long long t_loop0 = 0;
         if (VAR & 4096) t_loop0 = __builtin_amdgcn_s_memtime();
+        if constexpr (STAT) {
+            auto body = [&](auto slot_c, int u) __attribute__((always_inline)) {      // iteration u on ring slot u % 3 = slot_c (compile-time)
+                constexpr int SLOT = decltype(slot_c)::value;
+                dma_static(std::integral_constant<int, (SLOT + 2) % 3>{});          // unit u + 2; its buffer was last read in iteration u - 1
+                const char* Vs = smem + SLOT * BUFB;
+                step(Vs, std::false_type{}, 2 * u, sa, sb, pa, pb);
+                step(Vs, std::true_type{}, 2 * u + 1, sb, sa, pb, pa);
+                iteration_sync();
+            };
+            int u = 0;
+            for (; u + 3 <= NUF; u += 3) {
+                body(std::integral_constant<int, 0>{}, u);
+                body(std::integral_constant<int, 1>{}, u + 1);
+                body(std::integral_constant<int, 2>{}, u + 2);
+            }
+            if (u < NUF) {
+                body(std::integral_constant<int, 0>{}, u); ++u; ring = 1;
+                if (u < NUF) { body(std::integral_constant<int, 1>{}, u); ++u; ring = 2; }
+            }
+        } else
         for (int u = 0; u < NUF; ++u) {
             if (DMA) {
                 if (!(VAR & 16)) dma_unit(u + 2, ring == 0 ? 2 : ring - 1);      // buffer (u+2) % 3 was last read in iteration u-1
@@ -907,8 +973,16 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
             if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 262144>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 262144>(p, s);
             return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
 #endif
-        case 10:
-        default:
+        case 10:            // the round-3 default: one loop body, ring slot and staging bookkeeping at run time
+            if (p.proj_w == nullptr) {
+                if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192>(p, s);
+                return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
+            }
+            [[fallthrough]];
+        case 12:            // round 4 (default): the LDS-DMA kernel with the main loop unrolled over the three ring slots -- compile-time LDS
+        default:            // addresses, three-instruction staging pieces, no first / ragged-block test on interior steps
+            if (p.proj_w == nullptr && p.k_pad_one)
+                return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 2097152>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 2097152>(p, s);
             if (p.proj_w != nullptr) {      // fused out-projection (validated by imd_launch_attention)
                 if (p.k_pad_one) return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 1048576>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 1048576>(p, s);
                 return h ? launch_attn40<true, 8, 1 | 8192 | 1048576>(p, s) : launch_attn40<false, 8, 1 | 8192 | 1048576>(p, s);

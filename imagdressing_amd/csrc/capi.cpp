@@ -97,7 +97,7 @@ int imd_set_tuning(int knob, int value) {
 #ifdef IMD_ABLATIONS
             IMD_REQUIRE(value >= 1 && value <= 54, "set_tuning: attention variant for head dim 40 must be 1..54 (20..49: timing ablations, WRONG results; 50..54: correct but no faster)");
 #else
-            IMD_REQUIRE(value >= 1 && value <= 11, "set_tuning: attention variant for head dim 40 must be 1..11 (the timing ablations 20..49 and the measured no-gain variants 50..54 exist only in -DIMD_ABLATIONS builds)");
+            IMD_REQUIRE(value >= 1 && value <= 12, "set_tuning: attention variant for head dim 40 must be 1..12 (the timing ablations 20..49 and the measured no-gain variants 50..54 exist only in -DIMD_ABLATIONS builds)");
 #endif
             g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
@@ -133,6 +133,7 @@ static bool sized(const imd_conv_gemm_params* p) { return p && p->struct_bytes =
 int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch_supported(*p)) ? 1 : 0; }
 int imd_conv_patch2_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch2_supported(*p)) ? 1 : 0; }
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return sized(p) ? imd_conv_patch_stats_parts_of(*p) : 0; }
+int imd_conv_gemm_stats_parts(const imd_conv_gemm_params* p, int cfg) { return sized(p) ? imd_conv_gemm_stats_parts_of(*p, cfg) : 0; }
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_gemm_dma_supported(*p)) ? 1 : 0; }
 
 int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (sized(p) && (imd_row_linear_supported(*p) || imd_row_linear_k640_supported(*p) || imd_row_linear_k1280_supported(*p) || imd_row_qkv_supported(*p))) ? 1 : 0; }

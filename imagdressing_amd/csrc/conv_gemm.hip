@@ -328,6 +328,105 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvGemmParams
     }
 }
 
+// The same finish launch when the output feeds a GroupNorm (gn_stats_out, round 4): besides summing the slices and running the epilogue
+// it writes the GroupNorm statistics of the tensor it stores -- per (image, pixel part, group) fp32 (sum, sum of squares) of the
+// ROUNDED values, the layout imd_groupnorm consumes through `nparts` -- so the next group_norm skips its statistics launch (the
+// 16 x 16 / 8 x 8 levels: 19 of the 46 statistics launches of a denoising step).  norm.hip's scheme: a thread owns a FIXED 8-channel
+// column and walks pixel rows, so its two (group) accumulator pairs stay in registers; deterministic (no atomics).
+constexpr int FS_THREADS = 320;          // 5 waves: 40 / 80 / 160 / 320 columns divide evenly
+
+__host__ __device__ inline int fs_rows_per_part(int B, int HW, int N) {
+    const int cpr = N / 8, cols = cpr < FS_THREADS ? cpr : FS_THREADS, plan = FS_THREADS / cols;
+    int rpp = (int)(((long)B * HW + 511) / 512);          // ~512 blocks; never below one pass of the block's pixel lanes
+    rpp = (rpp + plan - 1) / plan * plan;
+    if (rpp < plan) rpp = plan;
+    return rpp;
+}
+
+template <bool F16>
+__global__ __launch_bounds__(FS_THREADS) void splitk_finish_stats_kernel(const ConvGemmParams p, int rpp, int nparts) {
+    using E = El<F16>;
+    __shared__ float red[FS_THREADS][4];
+    const int HWo = p.Hout * p.Wout;
+    const int cpr = p.N / 8, cols = min(cpr, FS_THREADS), plan = FS_THREADS / cols;
+    const int tid = threadIdx.x, part = blockIdx.x, b = blockIdx.y;
+    const int r0 = part * rpp, r1 = min(HWo, r0 + rpp);
+    const int G = p.gn_stats_groups, cpg = p.N / G;
+    const int my_col = tid % cols, my_pl = tid / cols;
+    const size_t slab = (size_t)p.M * p.N;
+    for (int cbase = 0; cbase < cpr; cbase += cols) {
+        const int vec = cbase + my_col, n = vec * 8;
+        const int g0 = n / cpg;
+        const int split = min(8, (g0 + 1) * cpg - n);      // channels [0, split) of the chunk -> group g0, the rest -> g0 + 1
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        if (my_pl < plan && vec < cpr) {
+            for (int row = r0 + my_pl; row < r1; row += plan) {
+                const int m = b * HWo + row;
+                float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int sl = 0; sl < p.split_k; ++sl) {
+                    const float* src = p.splitk_ws + sl * slab + (size_t)m * p.N + n;
+                    const float4 a = *reinterpret_cast<const float4*>(src);
+                    const float4 c = *reinterpret_cast<const float4*>(src + 4);
+                    v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += c.x; v[5] += c.y; v[6] += c.z; v[7] += c.w;
+                }
+                epilogue8<F16>(p, v, m, n, 8, HWo);            // v: the final fp32 values; the tensor holds them rounded to 16 bits
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r = E::tof(E::fromf(v[e]));
+                    if (e < split) { s0 += r; q0 += r * r; } else { s1 += r; q1 += r * r; }
+                }
+            }
+        }
+        red[tid][0] = s0; red[tid][1] = q0; red[tid][2] = s1; red[tid][3] = q1;
+        __syncthreads();
+        if (tid < G) {                                          // fixed fold order: column, then pixel lane
+            const int g = tid;
+            int vlo = (g * cpg) / 8, vhi = ((g + 1) * cpg - 1) / 8;
+            vlo = max(vlo, cbase); vhi = min(vhi, min(cpr, cbase + cols) - 1);
+            float S = 0.f, Q = 0.f;
+            for (int v = vlo; v <= vhi; ++v) {
+                const int vg0 = (v * 8) / cpg;
+                for (int pl = 0; pl < plan; ++pl) {
+                    const float* e = red[pl * cols + (v - cbase)];
+                    if (vg0 == g) { S += e[0]; Q += e[1]; }
+                    else if (vg0 + 1 == g) { S += e[2]; Q += e[3]; }
+                }
+            }
+            float* dst = p.gn_stats_out + (((size_t)b * nparts + part) * G + g) * 2;
+            if (cbase == 0) { dst[0] = S; dst[1] = Q; } else { dst[0] += S; dst[1] += Q; }
+        }
+        __syncthreads();
+    }
+}
+
+// statistic partials per image the finish launch writes (0: this problem cannot take the statistics form)
+int splitk_stats_parts_of(const ConvGemmParams& p) {
+    if (p.split_k <= 1 || p.splitk_counters != nullptr || p.mode != OUT_ROWMAJOR || p.out_f32 || p.act == ACT_GEGLU || (p.N % 8) ||
+        p.gn_stats_groups <= 0 || p.gn_stats_groups > 64 || p.N % p.gn_stats_groups || (p.N / p.gn_stats_groups) < 8 || p.Hout * p.Wout <= 0)
+        return 0;
+    const int HW = p.Hout * p.Wout, rpp = fs_rows_per_part(p.M / HW, HW, p.N);
+    return (HW + rpp - 1) / rpp;
+}
+
+// the second launch of a K-sliced problem: sum the slabs, run the epilogue (+ GroupNorm statistics of the output when asked for)
+int launch_splitk_finish(const ConvGemmParams& p, hipStream_t s, const char* what) {
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    if (p.gn_stats_out != nullptr) {
+        const int nparts = splitk_stats_parts_of(p);
+        if (nparts == 0) return imd_set_error("%s: gn_stats_out on a K-sliced problem that cannot produce the statistics", what);
+        const int HW = p.Hout * p.Wout, B = p.M / HW, rpp = fs_rows_per_part(B, HW, p.N);
+        if (h) hipLaunchKernelGGL(splitk_finish_stats_kernel<true>, dim3((unsigned)nparts, (unsigned)B), dim3(FS_THREADS), 0, s, p, rpp, nparts);
+        else hipLaunchKernelGGL(splitk_finish_stats_kernel<false>, dim3((unsigned)nparts, (unsigned)B), dim3(FS_THREADS), 0, s, p, rpp, nparts);
+        return imd_check_launch(what);
+    }
+    const long chunks = (long)p.M * ((p.N + 7) / 8);
+    long blocks = (chunks + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (h) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
+    return imd_check_launch(what);
+}
+
 template <bool F16, int BM, int BN, int BK, int WM, int WN, int DEPTH = 2>
 int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     static_assert(DEPTH == 2 || DEPTH == 4, "pipeline depth");
@@ -343,11 +442,7 @@ int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(WM * WN * 64), lds, s, p);
     int rc = imd_check_launch("conv_gemm");
     if (rc || p.split_k <= 1 || p.splitk_counters != nullptr) return rc;
-    const long chunks = (long)p.M * ((p.N + 7) / 8);
-    long blocks = (chunks + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel<F16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-    return imd_check_launch("conv_gemm split-K finish");
+    return launch_splitk_finish(p, s, "conv_gemm split-K finish");
 }
 
 int tile_dims(int cfg, int* bm, int* bn) {
@@ -379,6 +474,18 @@ int imd_gemm_pick_order(const ConvGemmParams& p, int n_tiles) {
     const double cost_m = a_split + 8.0 * w_bytes;
     const double cost_n = (n_tiles < 8 ? n_tiles : 8) * a_split + w_bytes;
     return cost_m <= cost_n ? 4 : 8;
+}
+
+// statistic partials per image a launch of `p` with tile config `cfg` writes through gn_stats_out (0: none): the halo-patch kernel's own
+// epilogue when it runs un-split, the finish launch of any K-sliced problem otherwise
+int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
+    ConvGemmParams p = p_in;
+    if (p.split_k < 1) p.split_k = 1;
+    if (p.split_k > 1) {
+        if (cfg == 21 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        return splitk_stats_parts_of(p);
+    }
+    return cfg == 5 ? imd_conv_patch_stats_parts_of(p) : 0;
 }
 
 int imd_conv_gemm_choose_cfg(int M, int N) {
@@ -439,9 +546,10 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     // GroupNorm statistics of the output (ABI v6+): only the halo-patch kernel's un-split epilogue produces them; every other request is an
     // ERROR -- a launch that silently skipped the write would leave the next imd_groupnorm(nparts > 0) reading uninitialised memory, and
     // gn_stats_groups = 0 / fewer than 8 channels per group would divide by zero / straddle more than two groups in the kernel
-    if (p.gn_stats_out != nullptr && (cfg != 5 || imd_conv_patch_stats_parts_of(p) == 0))
-        return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 without K slices, a row-major 16-bit output and 1 <= groups <= 64 with N %% groups == 0 "
-                             "and N / groups >= 8 (got cfg=%d split_k=%d groups=%d N=%d); ask imd_conv_patch_stats_parts() first", cfg, p.split_k, p.gn_stats_groups, p.N);
+    if (p.gn_stats_out != nullptr && imd_conv_gemm_stats_parts_of(p, cfg) == 0)
+        return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 without K slices or any K-sliced launch with a separate finish, a row-major 16-bit "
+                             "output and 1 <= groups <= 64 with N %% groups == 0 and N / groups >= 8 (got cfg=%d split_k=%d groups=%d N=%d); ask "
+                             "imd_conv_gemm_stats_parts() first", cfg, p.split_k, p.gn_stats_groups, p.N);
     if (p.splitk_counters != nullptr) {          // one counter per output tile; larger grids keep the two-launch path
         int bm = 128, bn = 128;
         if (cfg == 5) { bm = 128; bn = 128; } else tile_dims(cfg, &bm, &bn);
@@ -472,23 +580,13 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
             int rc = imd_launch_conv_patch(p, s);
             if (rc || p.split_k <= 1 || p.splitk_counters != nullptr) return rc;
-            const long chunks = (long)p.M * ((p.N + 7) / 8);
-            long blocks = (chunks + 255) / 256;
-            if (blocks > 2048) blocks = 2048;
-            if (h) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-            return imd_check_launch("conv_patch split-K finish");
+            return launch_splitk_finish(p, s, "conv_patch split-K finish");
         }
         case 21: {  // halo patch, 16 x 16 pixel tiles (conv_patch2.hip)
             p.splitk_counters = nullptr;
             int rc = imd_launch_conv_patch2(p, s);
             if (rc || p.split_k <= 1) return rc;
-            const long chunks = (long)p.M * ((p.N + 7) / 8);
-            long blocks = (chunks + 255) / 256;
-            if (blocks > 2048) blocks = 2048;
-            if (h) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-            return imd_check_launch("conv_patch2 split-K finish");
+            return launch_splitk_finish(p, s, "conv_patch2 split-K finish");
         }
         case 12: return imd_launch_row_linear(p, 0, 0.f, s);      // row-resident kernel (row_linear.hip): K = 320, N <= 320
         case 13: return imd_launch_row_linear_k640(p, 0, 0.f, s); // row-resident split-K kernel (row_linear_k640.hip): K = 640, N % 160 == 0
@@ -501,12 +599,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             p.splitk_counters = nullptr;
             int rc = imd_launch_gemm_dma128(p, cfg >= 19 ? 4 : 3, s);
             if (rc || p.split_k <= 1) return rc;
-            const long chunks = (long)p.M * ((p.N + 7) / 8);
-            long blocks = (chunks + 255) / 256;
-            if (blocks > 2048) blocks = 2048;
-            if (h) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-            return imd_check_launch("gemm_dma128 split-K finish");
+            return launch_splitk_finish(p, s, "gemm_dma128 split-K finish");
         }
         default: return imd_set_error("conv_gemm: unknown tile config %d", cfg);
     }

@@ -28,6 +28,7 @@ bool imd_conv_patch_supported(const ConvGemmParams& p);
 bool imd_conv_patch2_supported(const ConvGemmParams& p);      // conv_patch2.hip: 16 x 16 pixel tiles (tile config 21)
 int imd_launch_conv_patch2(const ConvGemmParams& p, hipStream_t s);
 int imd_conv_patch_stats_parts_of(const ConvGemmParams& p);
+int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p, int cfg);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
 bool imd_row_linear_supported(const ConvGemmParams& p);                                    // row_linear.hip
 int imd_launch_row_linear(const ConvGemmParams& p, int ln, float ln_eps, hipStream_t s);

@@ -183,8 +183,8 @@ def conv_gemm(
     of the input into the 3x3 halo-patch kernel (tile config 5).
     ``ln_eps``: LayerNorm WITHOUT affine over the K channels of every row of ``x`` is applied on the fly (row-resident kernel,
     K = 320 and N <= 320 only; fold gamma / beta into ``w`` / ``bias`` with :func:`fold_layernorm_affine`).
-    ``gn_stats_groups`` = G: when the launch lands on the halo-patch kernel without K slices, its epilogue also writes the GroupNorm(G)
-    statistics of the OUTPUT (per-tile fp32 partials); they ride on the returned tensor (``_imd_gn_stats``) and the next
+    ``gn_stats_groups`` = G: when the launch lands on the halo-patch kernel without K slices, or is K-sliced with a separate finish launch,
+    the epilogue / the finish launch also writes the GroupNorm(G) statistics of the OUTPUT (per-tile / per-pixel-part fp32 partials); they ride on the returned tensor (``_imd_gn_stats``) and the next
     :func:`group_norm` of that tensor skips its statistics pass.  Silently not produced on every other path (FUSED_GN_STATS = False: never).
     """
     ensure_device(x.device)
@@ -276,9 +276,9 @@ def conv_gemm(
         if SPLITK_IN_KERNEL:
             p.splitk_counters = splitk_counters(x.device).data_ptr()
     stats = None
-    if gn_stats_groups and FUSED_GN_STATS and cfg == 5 and split_k == 1 and heads is None and not out_f32 and act != ACT_GEGLU:
+    if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and (cfg == 5 or split_k > 1):
         p.gn_stats_groups = gn_stats_groups
-        nparts = lib.imd_conv_patch_stats_parts(C.byref(p))
+        nparts = lib.imd_conv_gemm_stats_parts(C.byref(p), cfg)       # halo-patch epilogue (un-split) or the finish launch of the K slices
         if nparts > 0:
             Bimg = M // (Hout * Wout)
             stats = (torch.empty((Bimg, nparts, gn_stats_groups, 2), dtype=torch.float32, device=x.device), nparts, gn_stats_groups)

@@ -429,7 +429,7 @@ class _Encoder(PretrainedMixin):
                     x = blk.attentions[j](x, ehs, cak)
                 skips.append(x)
             if blk.downsampler is not None:
-                x = blk.downsampler(x, stride=2)
+                x = blk.downsampler(x, stride=2, gn_stats_groups=self.cfg["norm_num_groups"])   # feeds the next level's norm1 (K-sliced: statistics from the finish launch)
                 skips.append(x)
         return x, skips
 

@@ -79,8 +79,8 @@ typedef struct imd_conv_gemm_params {
     int* splitk_counters; /* split_k > 1 only.  NULL: the K slices are summed by a second launch (fixed order).  Otherwise >=
                           * IMD_SPLITK_COUNTERS ints that are ZERO on entry and are left zero: every output tile's last-arriving
                           * workgroup sums the slices itself, in the same fixed order (bit-identical results, one launch less) */
-    /* GroupNorm statistics of the OUTPUT produced in the epilogue (cfg 5, split_k == 1, row-major 16-bit output, N %
-     * gn_stats_groups == 0): every workgroup writes the fp32 (sum, sum of squares) of its tile's final values per group to
+    /* GroupNorm statistics of the OUTPUT produced in the epilogue (cfg 5 with split_k == 1, or the finish launch of a K-sliced problem:
+     * imd_conv_gemm_stats_parts(); row-major 16-bit output, N % gn_stats_groups == 0): every workgroup writes the fp32 (sum, sum of squares) of its tile's final values per group to
      * gn_stats_out[((b * nparts + part) * G + g) * 2], part = (pixel tile of the image) * n_tiles + channel tile, nparts =
      * imd_conv_patch_stats_parts(); groups outside the tile get zeros.  The next imd_groupnorm on that tensor passes the buffer
      * as `partial` with `nparts` and skips its statistics pass (ResnetBlock2D: conv1 -> norm2, conv2 -> the next block's norm). */
@@ -256,6 +256,10 @@ int imd_conv_patch_supported(const imd_conv_gemm_params* p);
 int imd_conv_patch2_supported(const imd_conv_gemm_params* p);
 /* number of statistic partials per image the halo-patch kernel writes for this geometry (gn_stats_out), 0 if it cannot */
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p);
+/* the same for ANY launch: partials per image that imd_conv_gemm(p, cfg) writes through gn_stats_out -- the halo-patch epilogue (cfg 5, no K
+ * slices) or, with p->split_k > 1 and a separate finish launch (splitk_counters == NULL), the finish launch itself, which then sums the
+ * slices, runs the epilogue AND emits the statistics of the tensor it stores (row-major 16-bit outputs, N / groups >= 8); 0: none */
+int imd_conv_gemm_stats_parts(const imd_conv_gemm_params* p, int cfg);
 /* 1 iff tile config 16 (256 x 256 x 64 LDS-DMA tile kernel, gemm_dma.hip: plain linear layer, K % 64 == 0, no K split) can run *p. */
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p);
 

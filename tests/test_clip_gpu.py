@@ -222,7 +222,7 @@ def test_main_call_sequence_of_the_reference_script(hf):
     pipe = IMAGDressing_v1(unet=p["e_unet"], reference_unet=p["e_ref"], vae=vae, tokenizer=Tok(), text_encoder=text, image_encoder=vis,
                            ImgProj=proj, scheduler=noise_scheduler, safety_checker=None, feature_extractor=CLIPImageProcessor)
 
-    def resize_img(input_image, max_side=160, min_side=128, mode=Image.BILINEAR, base_pixel_number=64):      # :25-37 (sizes / 4 for the small config)
+    def resize_img(input_image, max_side=192, min_side=128, mode=Image.BILINEAR, base_pixel_number=64):      # :25-37 (640 x 512 -> 192 x 128 for the small config: SD latents need image sides divisible by 64)
         w, h = input_image.size
         ratio = min_side / min(h, w)
         w, h = round(ratio * w), round(ratio * h)
@@ -233,7 +233,7 @@ def test_main_call_sequence_of_the_reference_script(hf):
         return input_image.resize([w_resize_new, h_resize_new], mode)
 
     def img_transform(img):                       # transforms.Compose([Resize([H, W], BILINEAR), ToTensor(), Normalize([0.5], [0.5])]) (:158-162)
-        img = img.resize((128, 160), Image.BILINEAR)
+        img = img.resize((128, 192), Image.BILINEAR)
         x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1)
         return (x - 0.5) / 0.5
 
@@ -258,7 +258,7 @@ def test_main_call_sequence_of_the_reference_script(hf):
             null_prompt=null_prompt,
             negative_prompt=negative_prompt,
             width=128,
-            height=160,
+            height=192,
             num_images_per_prompt=num_samples,
             guidance_scale=7.5,
             image_scale=1.0,
@@ -268,9 +268,9 @@ def test_main_call_sequence_of_the_reference_script(hf):
     output = run()
     # ================= end =================
     assert isinstance(output, list) and len(output) == num_samples and isinstance(output[0], Image.Image)
-    assert output[0].size == (128, 160) and output[0].mode == "RGB"
-    save_output = [clothes_img.resize((128, 160), Image.BICUBIC), output[0]]          # :190-193 (image_grid pastes them side by side)
-    grid = Image.new("RGB", size=(2 * 128, 160))
+    assert output[0].size == (128, 192) and output[0].mode == "RGB"
+    save_output = [clothes_img.resize((128, 192), Image.BICUBIC), output[0]]          # :190-193 (image_grid pastes them side by side)
+    grid = Image.new("RGB", size=(2 * 128, 192))
     for i, img in enumerate(save_output):
         grid.paste(img, box=(i * 128, 0))
     arr = np.asarray(output[0])

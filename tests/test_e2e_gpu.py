@@ -203,10 +203,14 @@ def test_step_graph_replay_is_bit_identical(small_pair):
         pipe.enable_step_graph(True)
         g1 = run()
         g2 = run()
-        pipe.enable_step_graph(False)
+        assert getattr(pipe, "_last_step_graph", None) is not None      # the graph path really ran
+        side = pipe._graph_stream.cuda_stream
+        from imagdressing_amd import ops as _ops
+        assert any(k[-1] == side for k in _ops._ws), "the replayed step keeps its scratch buffers keyed by the side stream"
+        pipe.enable_step_graph(False)                                   # releases the graph, its stream and that stream's scratch buffers
+        assert getattr(pipe, "_last_step_graph", None) is None and not any(k[-1] == side for k in _ops._ws)
         assert torch.isfinite(eager).all()
         assert torch.equal(eager, g1) and torch.equal(eager, g2), (nimg, (eager - g1).abs().max().item())
-    assert getattr(pipe, "_last_step_graph", None) is not None          # the graph path really ran
 
 
 def _traj_bar(dtype):

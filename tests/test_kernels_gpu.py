@@ -525,9 +525,61 @@ def test_conv3x3_epilogue_groupnorm_statistics(ops, B, H, W, Cin, Cout, G, dt):
     ref = F.silu(F.group_norm(out.float().cpu().permute(0, 3, 1, 2), G, gamma, beta, eps=1e-5)).permute(0, 2, 3, 1)
     assert_close(fused, ref, atol=2 * TOL[dt], what="group_norm on producer statistics")
     assert_close(fused, plain.float(), atol=2 * TOL[dt], what="producer statistics vs own pass")
-    # K slices finish in another launch: no statistics, silently
+    # K slices: the statistics then come from the finish launch (round 4; test_splitk_finish_groupnorm_statistics)
     out2 = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=5, split_k=2 if Cin >= 64 else 1, gn_stats_groups=G)
-    assert (getattr(out2, "_imd_gn_stats", None) is None) == (Cin >= 64)
+    assert getattr(out2, "_imd_gn_stats", None) is not None
+
+
+@pytest.mark.parametrize("cfg,B,H,W,Cin,Cout,G,split,stride", [
+    (2, 8, 8, 8, 1280, 1280, 32, 6, 1),        # the 8x8-level weight-streaming conv of the bench batch (64^2 register-staged tiles)
+    (18, 2, 8, 8, 320, 1280, 32, 3, 1),        # gathering LDS-DMA tiles
+    (5, 2, 16, 16, 640, 1280, 32, 4, 1),       # halo-patch kernel with K slices
+    (21, 1, 32, 32, 640, 640, 32, 3, 1),       # 16 x 16-pixel-tile halo-patch kernel
+    (0, 2, 32, 32, 320, 320, 32, 2, 2),        # stride-2 downsample conv (feeds the next level's norm1)
+    (2, 3, 8, 8, 128, 96, 8, 2, 1),            # 12 channels per group: 8-channel chunks straddle groups
+    (0, 2, 16, 16, 64, 2560, 32, 2, 1),        # 320 columns: one full pass of the block
+])
+@DTS
+def test_splitk_finish_groupnorm_statistics(ops, cfg, B, H, W, Cin, Cout, G, split, stride, dt):
+    """A K-sliced convolution whose output feeds a GroupNorm: the finish launch (slice sum + bias / time-embedding vector / residual) also
+    emits the statistics of the tensor it stores; the tensor is bit-identical to the plain finish, the folded partials are the tensor's
+    moments, and the group_norm that consumes them equals F.group_norm of the stored tensor."""
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    Ho, Wo = H // stride, W // stride
+    b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, Ho, Wo, Cout).to(dt)
+    gamma = 1.0 + 0.2 * rnd(6, Cout); beta = 0.2 * rnd(7, Cout)
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    kw = dict(rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), cfg=cfg, split_k=split, stride=stride)
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), gn_stats_groups=G, **kw)
+    plain_out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), **kw)
+    assert getattr(plain_out, "_imd_gn_stats", None) is None
+    assert torch.equal(out, plain_out), "the statistics form of the finish launch must store the same tensor"
+    st = getattr(out, "_imd_gn_stats", None)
+    assert st is not None and st[2] == G
+    part, nparts, _ = st
+    assert tuple(part.shape) == (B, nparts, G, 2)
+    folded = part.double().sum(1).cpu()
+    o = out.double().cpu().permute(0, 3, 1, 2).reshape(B, G, -1)
+    n = o.shape[-1]
+    assert torch.allclose(folded[..., 0] / n, o.mean(-1), atol=1e-4), "group means"
+    assert torch.allclose(folded[..., 1] / n, (o * o).mean(-1), rtol=1e-4, atol=1e-4), "group second moments"
+    fused = ops.group_norm(out, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=True)
+    ref = F.silu(F.group_norm(out.float().cpu().permute(0, 3, 1, 2), G, gamma, beta, eps=1e-5)).permute(0, 2, 3, 1)
+    assert_close(fused, ref, atol=2 * TOL[dt], what="group_norm on the finish launch's statistics")
+    own = ops.group_norm(plain_out, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=True)
+    assert_close(fused, own.float(), atol=2 * TOL[dt], what="finish statistics vs own pass")
+    with pytest.raises(ops.L.ImdError):           # a request the launch cannot honour is an error at the C ABI, not a silent skip
+        p = dict(kw, cfg=0, split_k=1)
+        t = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), **p)
+        import ctypes
+        q = ops.L.ConvGemmParams()
+        q.x, q.w, q.out = xd.data_ptr(), dev(pack_conv(w)).data_ptr(), t.data_ptr()
+        q.M, q.N, q.K, q.Cin, q.taps = B * Ho * Wo, Cout, 9 * Cin, Cin, 9
+        q.Hin, q.Win, q.Hout, q.Wout, q.stride, q.x_pix_stride, q.out_ld, q.res_ld = H, W, Ho, Wo, stride, Cin, Cout, Cout
+        q.out_scale, q.split_k, q.dtype = 1.0, 1, (1 if dt == torch.float16 else 0)
+        q.gn_stats_out, q.gn_stats_groups = part.data_ptr(), G
+        ops.L.check(ops.L.load().imd_conv_gemm(ctypes.byref(q), 0, 0))
 
 
 @DTS
@@ -620,9 +672,9 @@ def test_attention(ops, D, B, N, L1, L2, dt):
     assert_close(out, ref, atol=1e-2, rtol=1e-2, what=f"attention D={D}")
 
 
-@pytest.mark.parametrize("variant", [10, 11, 9, 7])
+@pytest.mark.parametrize("variant", [10, 12, 11, 9, 7])
 @pytest.mark.parametrize("pad_one", [True, False])
-@pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (530, 700, 0), (512, 1000, 520)])
+@pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (530, 700, 0), (512, 1000, 520), (768, 1408, 1216), (512, 1344, 64)])
 @DTS
 def test_attention_d40_kernel_variants(ops, N, L1, L2, pad_one, variant, dt):
     """The software-pipelined head-dim-40 kernel (attention_d40.hip; N >= 512) in every shipped variant -- 10: head-dim rows
