@@ -195,109 +195,122 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     const bool wave_live = n0 + wn0 < p.N;
 
     if constexpr (DMA) {
+        // Round 4: the loop's bookkeeping cut to the bone -- it was 500 instructions per 32-channel chunk for 72 MFMAs (62 address adds, 42
+        // out-of-range selects, 63 s_mov + 42 s_nop of M0 save / restore and wait states, a divergent-branch skeleton around every tap):
+        //   * every LDS address of the loop is a compile-time offset from a loop-invariant register: the 9 x 2 x 2 activation-fragment
+        //     addresses (tap, pixel block, 16-deep slice) are computed ONCE, the chunk loop is unrolled over its two patch buffers and the
+        //     nine taps over the three weight-ring slots;
+        //   * a staging piece is three instructions (s_add m0 / s_nop / buffer_load ... lds) on a RUNNING source offset (+ one add per tap);
+        //     out-of-image halo pixels and channel rows past N carry the offset 2^31, which stays out of range under the running adds (the
+        //     operands are < 2 GiB: checked by the launcher); pieces staged past the last tap / chunk read in-range bytes nobody multiplies;
+        //   * the "this wave owns no valid channel" test (last channel tile of N = 320) is a scalar branch.
+        // Same MFMA order per accumulator as before: bit-identical results.
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
         const v4i_t dx = raw_rsrc(p.x, p.x_bytes), dw = raw_rsrc(p.w, p.w_bytes);
-        uint32_t a_src[3], w_src[2];          // byte offsets of this lane's 16-byte pieces at chunk 0 / tap 0 (OOB: zeros)
+        constexpr uint32_t FAR = 0x80000000u;
+        uint32_t acur[3], wcur[2];            // running source offsets: patch pieces of the NEXT chunk to stage, weight pieces of the next tap
+        uint32_t adst[3], wdst[2];            // LDS byte addresses of the pieces inside patch buffer 0 / ring slot 0 (wave-uniform)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int slot = (wv * 3 + i) * 64 + lane, pp = slot >> 2, piece = (slot & 3) ^ ((pp >> 2) & 3);
-            a_src[i] = OOB;
+            acur[i] = FAR;
             if (pp < NPIX) {
                 const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;        // logical pixel; the zero halo is applied AFTER the upsample
                 if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
                     const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;     // nearest-2x: source pixel = logical pixel >> 1
-                    a_src[i] = (uint32_t)(((b * p.Hin + sy) * p.Win + sx) * p.x_pix_stride + piece * 8) * 2u;
+                    acur[i] = (uint32_t)(((b * p.Hin + sy) * p.Win + sx) * p.x_pix_stride + piece * 8 + c_begin * CK) * 2u;
                 }
             }
+            adst[i] = smem_base + (uint32_t)((wv * 3 + i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int slot = (wv * 2 + i) * 64 + lane, row = slot >> 2, piece = (slot & 3) ^ ((row >> 2) & 3);
-            w_src[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8) * 2) : OOB;
+            wcur[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8 + c_begin * CK) * 2) : FAR;
+            wdst[i] = smem_base + (uint32_t)(2 * AB_D + (wv * 2 + i) * 1024);
         }
-        auto dma_patch = [&](int c, int buf) {
-#ifdef PATCH_T_NODMA
-            if (c > c_begin) return;
-#endif
+        const uint32_t w_tap = (uint32_t)(p.Cin * 2), w_chunk = (uint32_t)(CK * 2) - 8u * w_tap;      // next tap / tap 8 -> tap 0 of the next chunk
+        auto dma_patch = [&](auto buf_c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                dma16(dx, smem_base + buf * AB_D + (wv * 3 + i) * 1024, (a_src[i] != OOB && c < c_end) ? a_src[i] + (uint32_t)(c * CK * 2) : OOB);
+            for (int i = 0; i < 3; ++i) {
+                asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                             : : "v"(acur[i]), "s"(adst[i]), "s"(dx), "n"(decltype(buf_c)::value * AB_D) : "memory");
+                acur[i] += (uint32_t)(CK * 2);
+            }
         };
-        auto dma_w = [&](int it, int ring) {
-            const int cq = it / 9;
-#ifdef PATCH_T_WHOT
-            const uint32_t koff = 0; (void)cq;
-#else
-            const uint32_t koff = (uint32_t)(((it - cq * 9) * p.Cin + (c_begin + cq) * CK) * 2);
-#endif
-#ifdef PATCH_T_NODMA
-            if (it >= 2) return;
-#endif
+        auto dma_w = [&](auto ring_c, auto cross_c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                dma16(dw, smem_base + 2 * AB_D + ring * WB_D + (wv * 2 + i) * 1024, (w_src[i] != OOB && it < total) ? w_src[i] + koff : OOB);
+            for (int i = 0; i < 2; ++i) {
+                asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                             : : "v"(wcur[i]), "s"(wdst[i]), "s"(dw), "n"(decltype(ring_c)::value * WB_D) : "memory");
+                wcur[i] += decltype(cross_c)::value ? w_chunk : w_tap;
+            }
         };
-        int w_fr[2], a_row[2];
+        // fragment addresses (bytes inside a patch buffer / a ring slot), all loop-invariant
+        int w_fr[2], xa[9][2];            // 16-deep slice kk = 0; kk = 1 is the same address ^ 32 (one VALU in the loop instead of 20 more live registers)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int row = wn0 + a * 32 + col;
-            w_fr[a] = row * 64 + ((hi ^ ((row >> 2) & 3)) << 4);         // 16-deep slice kk = 0; kk = 1 is the same address ^ 32
+            w_fr[a] = row * 64 + ((hi ^ ((row >> 2) & 3)) << 4);
         }
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
-            const int q = wm0 + bb * 32 + cpix;
-            a_row[bb] = (q / TW) * PW + (q % TW);
+            const int q = wm0 + bb * 32 + cpix, r0 = (q / TW) * PW + (q % TW);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int rw = r0 + (t / 3) * PW + (t % 3);
+                xa[t][bb] = rw * 64 + ((hi ^ ((rw >> 2) & 3)) << 4);
+            }
         }
+        const bool live = __builtin_amdgcn_readfirstlane((int)(n0 + (wv & 1) * 64 < p.N)) != 0;      // scalar: the whole wave or nothing
+        const std::integral_constant<int, 0> i0{}; const std::integral_constant<int, 1> i1{}; const std::integral_constant<int, 2> i2{};
         if (total > 0) {
-            dma_patch(c_begin, 0);
-            dma_w(0, 0);
-            dma_w(1, 1);
+            dma_patch(i0);
+            dma_w(i0, std::false_type{});
+            dma_w(i1, std::false_type{});
         }
         dma_wait();
         __syncthreads();
-#pragma unroll 1
-        for (int cc = 0; cc < c_end - c_begin; ++cc) {
-            const int ab = cc & 1;
+        auto chunk = [&](auto ab_c) __attribute__((always_inline)) {       // one 32-channel chunk out of patch buffer ab_c
+            constexpr int AB = decltype(ab_c)::value;
+            const char* As = smem + AB * AB_D;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {                  // 9 taps = 3 turns of the weight ring: ring slots are compile-time
-                dma_w(cc * 9 + t + 2, (t + 2) % 3);
-                if (t == 5) dma_patch(c_begin + cc + 1, ab ^ 1);       // (always 3 pieces, zeros past the last chunk: the counted waits rely on it)
-#ifdef PATCH_T_NOMFMA
-                if (wave_live && p.M < 0) {
-#else
-                if (wave_live) {
-#endif
-                    const char* As = smem + ab * AB_D;
+                if (t % 3 == 0) dma_w(i2, std::false_type{});
+                else if (t % 3 == 1) dma_w(i0, std::false_type{});
+                else dma_w(i1, std::false_type{});
+                if (t == 6) { wcur[0] += w_chunk - w_tap; wcur[1] += w_chunk - w_tap; }     // (the piece just staged was tap 8: the next one is tap 0 of the next chunk)
+                if (t == 5) dma_patch(std::integral_constant<int, AB ^ 1>{});              // (always 3 pieces: the counted waits rely on it)
+                if (live) {
                     const char* Ws = smem + 2 * AB_D + (t % 3) * WB_D;
-                    int xa[2];
+                    uint4 wf[2][2], xf[2][2];
 #pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) {
-                        const int rw = a_row[bb] + (t / 3) * PW + (t % 3);
-                        xa[bb] = rw * 64 + ((hi ^ ((rw >> 2) & 3)) << 4);
+                    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) wf[kk][a] = *reinterpret_cast<const uint4*>(Ws + (w_fr[a] ^ (kk * 32)));
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) xf[kk][bb] = *reinterpret_cast<const uint4*>(As + (xa[t][bb] ^ (kk * 32)));
                     }
 #pragma unroll
-                    for (int kk = 0; kk < CK / 16; ++kk) {
-                        uint4 wf[2], xf[2];
-#pragma unroll
-                        for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + (w_fr[a] ^ (kk * 32)));
-#pragma unroll
-                        for (int bb = 0; bb < 2; ++bb) xf[bb] = *reinterpret_cast<const uint4*>(As + (xa[bb] ^ (kk * 32)));
+                    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                         for (int a = 0; a < 2; ++a)
 #pragma unroll
-                            for (int bb = 0; bb < 2; ++bb) acc[a][bb] = E::mfma(wf[a], xf[bb], acc[a][bb]);
-                    }
+                            for (int bb = 0; bb < 2; ++bb) acc[a][bb] = E::mfma(wf[kk][a], xf[kk][bb], acc[a][bb]);
                 }
                 // the next tap's weight pieces have landed: everything but this tap's two pieces (and, at taps 5 and 6, the three
                 // patch pieces issued behind them at tap 5) may stay in flight
                 if (t == 5 || t == 6) dma_wait_keep5(); else dma_wait_keep2();
-#ifndef PATCH_T_NOBAR
                 __syncthreads();
-#endif
             }
-        }
-        dma_wait();                  // zero-fill pieces past the end are still landing: the epilogue reuses this LDS
+        };
+        const int nch = c_end - c_begin;
+        int cc = 0;
+#pragma unroll 1
+        for (; cc + 2 <= nch; cc += 2) { chunk(i0); chunk(i1); }
+        if (cc < nch) chunk(i0);
+        dma_wait();                  // pieces staged past the end are still landing: the epilogue reuses this LDS
         __syncthreads();
     } else {
     if (total > 0) {
