@@ -417,7 +417,7 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
                 asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
-                             : : "v"(scur[i]), "s"(sdst[i]), "s"(sdsc[i]), "n"(SLOT * BUF_D) : "memory");
+                             : : "v"(scur[i]), "s"(sdst[i]), "s"(sdsc[i]), "n"(SLOT * BUF_D) : "memory", "scc");
                 scur[i] += sstr[i];
             }
         };

@@ -454,6 +454,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 3: case 7: *bm = 64; *bn = 64; return 0;
         case 6: *bm = 64; *bn = 320; return 0;
         case 9: case 21: *bm = 256; *bn = 128; return 0;
+        case 22: *bm = 128; *bn = 160; return 0;
         case 10: case 16: *bm = 256; *bn = 256; return 0;
         case 17: case 18: case 19: case 20: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
@@ -482,7 +483,7 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     return cfg == 5 ? imd_conv_patch_stats_parts_of(p) : 0;
@@ -587,6 +588,12 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             int rc = imd_launch_conv_patch2(p, s);
             if (rc || p.split_k <= 1) return rc;
             return launch_splitk_finish(p, s, "conv_patch2 split-K finish");
+        }
+        case 22: {  // halo patch, 8 x 16 pixels x 160 channels (conv_patch3.hip): N = 320 k without idle waves
+            int rc = imd_launch_conv_patch3(p, s);
+            if (rc || p.split_k <= 1) return rc;
+            p.splitk_counters = nullptr;
+            return launch_splitk_finish(p, s, "conv_patch3 split-K finish");
         }
         case 12: return imd_launch_row_linear(p, 0, 0.f, s);      // row-resident kernel (row_linear.hip): K = 320, N <= 320
         case 13: return imd_launch_row_linear_k640(p, 0, 0.f, s); // row-resident split-K kernel (row_linear_k640.hip): K = 640, N % 160 == 0

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
-                             : : "v"(acur[i]), "s"(adst[i]), "s"(dx), "n"(decltype(buf_c)::value * AB_D) : "memory");
+                             : : "v"(acur[i]), "s"(adst[i]), "s"(dx), "n"(decltype(buf_c)::value * AB_D) : "memory", "scc");
                 acur[i] += (uint32_t)(CK * 2);
             }
         };
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
-                             : : "v"(wcur[i]), "s"(wdst[i]), "s"(dw), "n"(decltype(ring_c)::value * WB_D) : "memory");
+                             : : "v"(wcur[i]), "s"(wdst[i]), "s"(dw), "n"(decltype(ring_c)::value * WB_D) : "memory", "scc");
                 wcur[i] += decltype(cross_c)::value ? w_chunk : w_tap;
             }
         };
@@ -492,7 +492,8 @@ int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
     const bool h = p.dtype == IMD_DTYPE_F16;
     // LDS-DMA staging of both operands unless the fused GroupNorm prologue (values needed in registers) is asked for, or tuning knob 2
     // bit 9 selects the round-1/2 register-staged form (A/B)
-    const bool dma = p.gn_a == nullptr && !(g_gemm_flags & 512);
+    const bool dma = p.gn_a == nullptr && !(g_gemm_flags & 512) && (p.ups || (p.x_bytes < 0x80000000u && p.w_bytes < 0x80000000u));   // (the DMA loop marks out-of-range pieces with offset 2^31)
+    if (p.ups && (p.x_bytes >= 0x80000000u || p.w_bytes >= 0x80000000u)) return imd_set_error("conv_patch: fused upsample needs operands < 2 GiB");
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = dma ? (h ? conv3x3_patch_kernel<true, true> : conv3x3_patch_kernel<false, true>)
                             : (h ? conv3x3_patch_kernel<true, false> : conv3x3_patch_kernel<false, false>);

@@ -1,0 +1,241 @@
+// 3x3 / stride-1 convolution, halo patch in LDS, 8 x 16 output pixels x 160 channels per workgroup (gfx950; tile config 22, round 4).
+//
+// Why another tile: the UNet's level-0 convolutions write N = 320 channels.  With conv_patch.hip's 128-channel tiles that is 2.5 tiles:
+// every third workgroup owns 64 valid channels, two of its four waves idle, and a sixth of the launch's wave slots does nothing
+// ("narrow last channel tile").  N = 320 = 2 x 160, and the bench batch's 64 x 64 maps give 256 pixel tiles of
+// 8 x 16: 512 workgroups of 128 pixels x 160 channels fill the chip's 512 slots (two 55 KB workgroups per CU) exactly, with no idle
+// wave and no padded MFMA.
+//
+//   workgroup: 4 waves, wave w = pixels [32 w, 32 w + 32) (two image rows of the tile) x ALL 160 channels = acc[5] f32x16 (80 VGPRs):
+//              per 16-deep slice one activation fragment feeds five MFMAs (6 ds_read_b128 per 5 MFMAs), ten MFMAs per tap and
+//              barrier instead of eight;
+//   LDS: halo patch (8+2) x (16+2) pixels x 32 channels = 180 rows x 64 B, double-buffered over channel chunks (2 x 12 KB), weight
+//        tile of a tap 160 rows x 64 B in a ring of three (3 x 10 KB): 54 KB -> two workgroups per CU;
+//   both operands by LDS-DMA with conv_patch.hip's source-side swizzle (piece c of row r at c ^ ((r >> 2) & 3)) and its round-4 loop
+//   form: every LDS address a compile-time offset from a loop-invariant register, three-instruction staging pieces on running source
+//   offsets (2^31 = out of range for halo pixels / channel rows past N), counted waits; fused nearest-2x upsample; K slices over
+//   channel chunks (fp32 slabs + the shared finish launch); epilogue shared with conv_gemm.hip, 64 pixels at a time through LDS.
+// Same K order and the same MFMA sequence per accumulator as conv_patch.hip: bit-identical results.
+#include <type_traits>
+
+#include "gemm_common.h"
+#include "lds_dma.h"
+
+namespace {
+
+constexpr int T3H = 8, T3W = 16;
+constexpr int P3W = T3W + 2, P3H = T3H + 2;
+constexpr int NPIX3 = P3H * P3W;               // 180 patch pixels
+constexpr int CK3 = 32;
+constexpr int BN3 = 160;
+constexpr int AB3 = 12 * 1024;                 // 180 rows x 64 B = 11.25 pieces -> 12 (three per wave; rows past 179 are never read)
+constexpr int WB3 = BN3 * 64, NWR3 = 3;        // 10 pieces per tap
+constexpr int PATCH3_LDS = 2 * AB3 + NWR3 * WB3;      // 55,296
+constexpr int CLD3 = BN3 + 4;
+constexpr int EROWS3 = 64;
+static_assert(PATCH3_LDS >= EROWS3 * CLD3 * 4, "the epilogue tile must fit the main-loop LDS");
+// MFMA column (lane & 31) -> pixel of a 2 x 16 pixel block: conv_patch.hip's permutation (conflict-free ds_read_b128 groups)
+__device__ constexpr unsigned char kColPix3[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7,
+                                                   30, 31, 16, 17, 22, 23, 24, 25, 26, 27, 28, 29, 18, 19, 20, 21};
+
+template <bool F16>
+__global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmParams p) {
+    using E = El<F16>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int hi = lane >> 5, col = lane & 31;
+    const int cpix = kColPix3[col];
+
+    const int H = p.Hout, W = p.Wout;          // output map = logical input map (fused nearest-2x upsample: twice the stored input)
+    const int tiles_x = (W + T3W - 1) / T3W, tiles_y = (H + T3H - 1) / T3H;      // ragged maps: tiles hang over the edge (zeros in, no stores out)
+    const int n_tiles = (p.N + BN3 - 1) / BN3;
+    int bid, tile_n;
+    xcd_tile_order(p.flags, (int)(gridDim.x / n_tiles), n_tiles, bid, tile_n);  // bid = pixel-tile index
+    const int tx = bid % tiles_x; bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y0 = ty * T3H, x0 = tx * T3W, n0 = tile_n * BN3;
+
+    const int nchunks = p.Cin / CK3;
+    const int split = blockIdx.y;
+    const int per = (nchunks + p.split_k - 1) / p.split_k;
+    const int c_begin = split * per;
+    const int c_end = min(nchunks, c_begin + per);
+    const int total = (c_end - c_begin) * 9;
+
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
+    const v4i_t dx = raw_rsrc(p.x, p.x_bytes), dw = raw_rsrc(p.w, p.w_bytes);
+    constexpr uint32_t FAR = 0x80000000u;      // out of range, and still out of range after the loop's running adds (operands < 2 GiB)
+    uint32_t acur[3], wcur[3];                 // running source offsets: patch pieces of the NEXT chunk to stage, weight pieces of the next tap
+    uint32_t adst[3], wdst[3];                 // LDS byte addresses of the pieces inside patch buffer 0 / ring slot 0 (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int slot = (wv * 3 + i) * 64 + lane, pp = slot >> 2, piece = (slot & 3) ^ ((pp >> 2) & 3);
+        acur[i] = FAR;
+        if (pp < NPIX3) {
+            const int iy = y0 - 1 + pp / P3W, ix = x0 - 1 + pp % P3W;      // logical pixel; the zero halo is applied AFTER the upsample
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+                acur[i] = (uint32_t)(((b * p.Hin + sy) * p.Win + sx) * p.x_pix_stride + piece * 8 + c_begin * CK3) * 2u;
+            }
+        }
+        adst[i] = smem_base + (uint32_t)((wv * 3 + i) * 1024);
+    }
+    // ten weight pieces per tap over four waves: wave w issues pieces w, w + 4 and min(w + 8, 9) -- waves 2 and 3 re-fetch piece 9 (the same
+    // bytes to the same place, a benign duplicate), so that every wave issues exactly three pieces per tap and the counted waits are uniform
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int pc = min(wv + 4 * i, 9);
+        const int slot = pc * 64 + lane, row = slot >> 2, piece = (slot & 3) ^ ((row >> 2) & 3);
+        wcur[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8 + c_begin * CK3) * 2) : FAR;
+        wdst[i] = smem_base + (uint32_t)(2 * AB3 + pc * 1024);
+    }
+    const uint32_t w_tap = (uint32_t)(p.Cin * 2), w_chunk = (uint32_t)(CK3 * 2) - 8u * w_tap;      // next tap / tap 8 -> tap 0 of the next chunk
+    auto dma_patch = [&](auto buf_c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                         : : "v"(acur[i]), "s"(adst[i]), "s"(dx), "n"(decltype(buf_c)::value * AB3) : "memory", "scc");
+            acur[i] += (uint32_t)(CK3 * 2);
+        }
+    };
+    auto dma_w = [&](auto ring_c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
+                         : : "v"(wcur[i]), "s"(wdst[i]), "s"(dw), "n"(decltype(ring_c)::value * WB3) : "memory", "scc");
+            wcur[i] += w_tap;
+        }
+    };
+
+    f32x16 acc[5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+
+    // fragment addresses (bytes inside a ring slot / a patch buffer), loop-invariant; the 16-deep slice kk = 1 is the same address ^ 32.
+    // Weight row a * 32 + col has the swizzle term of row col (a * 32 / 4 is a multiple of 4), so block a is a compile-time offset.
+    const int w_fr = col * 64 + ((hi ^ ((col >> 2) & 3)) << 4);
+    int xa[9];
+    {
+        const int q = 32 * wave + cpix, r0 = (q / T3W) * P3W + (q % T3W);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int rw = r0 + (t / 3) * P3W + (t % 3);
+            xa[t] = rw * 64 + ((hi ^ ((rw >> 2) & 3)) << 4);
+        }
+    }
+    const std::integral_constant<int, 0> i0{}; const std::integral_constant<int, 1> i1{}; const std::integral_constant<int, 2> i2{};
+    if (total > 0) {
+        dma_patch(i0);
+        dma_w(i0);
+        dma_w(i1);
+    }
+    dma_wait();
+    __syncthreads();
+    auto chunk = [&](auto ab_c) __attribute__((always_inline)) {       // one 32-channel chunk out of patch buffer ab_c
+        constexpr int AB = decltype(ab_c)::value;
+        const char* As = smem + AB * AB3;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {                  // 9 taps = 3 turns of the weight ring: ring slots are compile-time
+            if (t % 3 == 0) dma_w(i2); else if (t % 3 == 1) dma_w(i0); else dma_w(i1);
+            if (t == 6) {                              // (the tap just staged was tap 8: the next one is tap 0 of the next chunk)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) wcur[i] += w_chunk - w_tap;
+            }
+            if (t == 5) dma_patch(std::integral_constant<int, AB ^ 1>{});          // (always 3 pieces: the counted waits rely on it)
+            const char* Ws = smem + 2 * AB3 + (t % 3) * WB3;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint4 xf = *reinterpret_cast<const uint4*>(As + (xa[t] ^ (kk * 32)));
+                uint4 wf[5];
+#pragma unroll
+                for (int a = 0; a < 5; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + a * 2048 + (w_fr ^ (kk * 32)));
+#pragma unroll
+                for (int a = 0; a < 5; ++a) acc[a] = E::mfma(wf[a], xf, acc[a]);
+            }
+            // the next tap's weight pieces have landed: everything but this tap's three pieces (and, at taps 5 and 6, the three patch
+            // pieces issued behind them at tap 5) may stay in flight
+            if (t == 5 || t == 6) dma_wait_keep_n<6>(); else dma_wait_keep_n<3>();
+            __syncthreads();
+        }
+    };
+    const int nch = c_end - c_begin;
+    int cc = 0;
+#pragma unroll 1
+    for (; cc + 2 <= nch; cc += 2) { chunk(i0); chunk(i1); }
+    if (cc < nch) chunk(i0);
+    dma_wait();                  // pieces staged past the end are still landing: the epilogue reuses this LDS
+    __syncthreads();
+
+    // ---- epilogue (conv_gemm.hip's scheme): 64 pixels (two waves) at a time through LDS, 8 consecutive channels per thread ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CPR = BN3 / 8;                   // 20 chunks per pixel row
+    constexpr int CHUNKS = EROWS3 * CPR;           // 1280
+    const int HW = H * W;
+    float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)split * p.M * p.N : nullptr;
+#pragma unroll 1
+    for (int wr = 0; wr < 2; ++wr) {
+        if ((wave >> 1) == wr) {
+            const int row_l = (wave & 1) * 32 + cpix;
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float4*>(Cs + row_l * CLD3 + a * 32 + 8 * j + 4 * hi) =
+                        make_float4(acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]);
+        }
+        __syncthreads();
+        for (int ch = tid; ch < CHUNKS; ch += 256) {
+            const int row = ch / CPR, cc8 = (ch - row * CPR) * 8;
+            const int q = wr * EROWS3 + row;
+            const int oy = y0 + q / T3W, ox = x0 + q % T3W;
+            const int n = n0 + cc8;
+            if (n >= p.N || oy >= H || ox >= W) continue;
+            const int m = (b * H + oy) * W + ox;
+            const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD3 + cc8);
+            const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD3 + cc8 + 4);
+            if (slab) {
+                slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, false);
+            } else {
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HW);
+            }
+        }
+        if (wr == 0) __syncthreads();
+    }
+}
+
+}  // namespace
+
+bool imd_conv_patch3_supported(const ConvGemmParams& p) {
+    const bool geom = p.ups ? (p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win) : (p.Hin == p.Hout && p.Win == p.Wout);
+    return p.taps == 9 && p.stride == 1 && !p.pad_br_only && geom && p.Hout >= T3H && p.Wout >= T3W && (p.Cin % CK3) == 0 &&
+           p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU && p.gn_a == nullptr && (p.x_pix_stride % 8) == 0 &&
+           p.x_bytes < 0x80000000u && p.w_bytes < 0x80000000u;
+}
+
+int imd_launch_conv_patch3(const ConvGemmParams& p_in, hipStream_t s) {
+    ConvGemmParams p = p_in;
+    p.splitk_counters = nullptr;            // (K slices always finish with the shared second launch)
+    p.gn_stats_out = nullptr;               // (un-split statistics come from conv_patch.hip's epilogue only; validated by the dispatcher)
+    if (!imd_conv_patch3_supported(p))
+        return imd_set_error("conv_patch3: unsupported geometry (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 32 == 0, row-major output, operands < 2 GiB)");
+    static bool attr_set[2] = {false, false};
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    typedef void (*kern_t)(const ConvGemmParams);
+    const kern_t kern = h ? conv3x3_patch3_kernel<true> : conv3x3_patch3_kernel<false>;
+    if (!attr_set[h]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PATCH3_LDS);
+        if (e != hipSuccess) return imd_set_error("conv_patch3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set[h] = true;
+    }
+    const int B = p.M / (p.Hout * p.Wout);
+    const long blocks = (long)B * ((p.Hout + T3H - 1) / T3H) * ((p.Wout + T3W - 1) / T3W) * ((p.N + BN3 - 1) / BN3);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH3_LDS, s, p);
+    return imd_check_launch("conv_patch3");
+}

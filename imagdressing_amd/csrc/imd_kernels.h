@@ -27,6 +27,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
 bool imd_conv_patch_supported(const ConvGemmParams& p);
 bool imd_conv_patch2_supported(const ConvGemmParams& p);      // conv_patch2.hip: 16 x 16 pixel tiles (tile config 21)
 int imd_launch_conv_patch2(const ConvGemmParams& p, hipStream_t s);
+bool imd_conv_patch3_supported(const ConvGemmParams& p);      // conv_patch3.hip: 8 x 16 pixels x 160 channels (tile config 22)
+int imd_launch_conv_patch3(const ConvGemmParams& p, hipStream_t s);
 int imd_conv_patch_stats_parts_of(const ConvGemmParams& p);
 int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p, int cfg);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);

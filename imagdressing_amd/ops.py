@@ -263,6 +263,8 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg == 21 and not lib.imd_conv_patch2_supported(C.byref(p)):
                 cfg, split_k = -1, 0
+            if cfg == 22 and not lib.imd_conv_patch3_supported(C.byref(p)):
+                cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
     if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and Wout >= PATCH_MIN_W and N >= 64 \

@@ -204,7 +204,8 @@ int imd_device_check(int device);
  * kernels; 16: 256x256x64 and 17: 128x128x32 with a three-stage ring, both operands staged by LDS-DMA (plain linear layers, K % 64 == 0);
  * 18: the gathering form of 17 for 3x3 convolutions (stride 1 | 2, Cin % 32 == 0; K slices allowed for 17 and 18);
  * 19 / 20: 17 / 18 with a four-stage ring (64 KB, two workgroups per CU, three tiles of lead);
- * 21: the halo-patch kernel with 16 x 16 pixel tiles (256 pixels x 128 channels per workgroup, wave tiles 128 x 64: half the weight bytes per MAC).
+ * 21: the halo-patch kernel with 16 x 16 pixel tiles (256 pixels x 128 channels per workgroup, wave tiles 128 x 64: half the weight bytes per MAC);
+ * 22: the halo-patch kernel with 8 x 16 pixels x 160 channels per workgroup (wave tiles 32 x 160: N = 320 k runs without idle waves or padded MFMAs).
  * Results are identical up to fp32 summation order. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);
@@ -254,6 +255,8 @@ int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* co
 int imd_conv_patch_supported(const imd_conv_gemm_params* p);
 /* 1 iff tile config 21 (the halo-patch kernel with 16 x 16 pixel tiles, conv_patch2.hip) takes this geometry */
 int imd_conv_patch2_supported(const imd_conv_gemm_params* p);
+/* 1 iff tile config 22 (the halo-patch kernel with 160-channel tiles, conv_patch3.hip: N = 320 k without idle waves) takes this geometry */
+int imd_conv_patch3_supported(const imd_conv_gemm_params* p);
 /* number of statistic partials per image the halo-patch kernel writes for this geometry (gn_stats_out), 0 if it cannot */
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p);
 /* the same for ANY launch: partials per image that imd_conv_gemm(p, cfg) writes through gn_stats_out -- the halo-patch epilogue (cfg 5, no K

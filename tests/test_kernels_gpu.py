@@ -474,6 +474,38 @@ def test_conv3x3_halo_patch_256_pixel_tiles(ops, B, H, W, Cin, Cout, split, ups,
         ops.conv2d_nhwc(dev(rnd(1, 1, 8, 16, 32).to(dt)), dev(rnd(2, 32, 288).to(dt)), None, cfg=21)        # H < 16
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,split,ups", [
+    (1, 64, 64, 320, 320, 1, False), (2, 32, 32, 640, 320, 1, False), (2, 16, 16, 64, 160, 1, False), (3, 8, 16, 96, 132, 1, False),
+    (2, 16, 16, 640, 640, 4, False), (1, 16, 32, 1280, 1280, 8, False), (2, 16, 16, 960, 320, 3, False), (1, 8, 16, 32, 36, 1, False),
+    # ragged maps (tiles hang over the right / bottom edge) and the fused nearest-2x upsample (H, W = the STORED map)
+    (1, 96, 72, 320, 320, 1, False), (2, 48, 36, 640, 640, 2, False), (1, 17, 19, 32, 40, 1, False),
+    (1, 8, 8, 64, 320, 1, True), (2, 16, 16, 640, 640, 2, True), (1, 12, 18, 32, 200, 1, True)])
+@DTS
+def test_conv3x3_halo_patch_160_channel_tiles(ops, B, H, W, Cin, Cout, split, ups, dt):
+    """tile config 22 (conv_patch3.hip: 8 x 16 pixels x 160 channels per workgroup, wave tiles 32 x 160) == F.conv2d with the full
+    epilogue, K slices, ragged maps, channel counts that are not multiples of 160 and the fused upsample; bit-identical to the
+    128-channel-tile kernel (same K order and MFMA sequence per output element)"""
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, Ho, Wo, Cout).to(dt)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), b, padding=1).permute(0, 2, 3, 1) + temb[:, None, None, :] + res.float()
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    kw = dict(rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), ups=ups, split_k=split)
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=22, **kw)
+    assert tuple(out.shape) == (B, Ho, Wo, Cout)
+    assert_close(out, ref, what=f"160-channel halo-patch conv split={split} ups={ups}")
+    assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=5, **kw)), "differs from the 128-channel tile kernel"
+    if split > 1:         # K slices: the finish launch can emit the GroupNorm statistics for this tile config as well
+        G = 4 if Cout % 32 else 32
+        if Cout % G == 0 and Cout // G >= 8:
+            st_out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=22, gn_stats_groups=G, **kw)
+            assert torch.equal(st_out, out) and getattr(st_out, "_imd_gn_stats", None) is not None
+    with pytest.raises(ops.L.ImdError):
+        ops.conv2d_nhwc(dev(rnd(1, 1, 8, 8, 32).to(dt)), dev(rnd(2, 32, 288).to(dt)), None, cfg=22)        # W < 16
+
+
 @pytest.mark.parametrize("silu", [False, True])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 16, 64, 64), (2, 32, 32, 320, 320), (1, 16, 32, 960, 640)])
 @DTS
