@@ -455,6 +455,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 6: *bm = 64; *bn = 320; return 0;
         case 9: case 21: *bm = 256; *bn = 128; return 0;
         case 22: *bm = 128; *bn = 160; return 0;
+        case 23: *bm = 256; *bn = 160; return 0;
         case 10: case 16: *bm = 256; *bn = 256; return 0;
         case 17: case 18: case 19: case 20: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
@@ -483,9 +484,10 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || cfg == 22 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || cfg == 23 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
+    if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
     return cfg == 5 ? imd_conv_patch_stats_parts_of(p) : 0;
 }
 
@@ -589,8 +591,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             if (rc || p.split_k <= 1) return rc;
             return launch_splitk_finish(p, s, "conv_patch2 split-K finish");
         }
-        case 22: {  // halo patch, 8 x 16 pixels x 160 channels (conv_patch3.hip): N = 320 k without idle waves
-            int rc = imd_launch_conv_patch3(p, s);
+        case 22: case 23: {  // halo patch x 160 channels (conv_patch3.hip): 22 = 8 x 16 pixels, four waves; 23 = 16 x 16 pixels, eight waves (one weight tile per 256 pixels)
+            int rc = cfg == 22 ? imd_launch_conv_patch3(p, s) : imd_launch_conv_patch4(p, s);
             if (rc || p.split_k <= 1) return rc;
             p.splitk_counters = nullptr;
             return launch_splitk_finish(p, s, "conv_patch3 split-K finish");

@@ -16,6 +16,12 @@
 //   offsets (2^31 = out of range for halo pixels / channel rows past N), counted waits; fused nearest-2x upsample; K slices over
 //   channel chunks (fp32 slabs + the shared finish launch); epilogue shared with conv_gemm.hip, 64 pixels at a time through LDS.
 // Same K order and the same MFMA sequence per accumulator as conv_patch.hip: bit-identical results.
+//
+// NW = 8 (tile config 23): the same wave tile with EIGHT waves = 16 x 16 pixels x 160 channels per workgroup, one workgroup per CU.  The
+// level-0 convolutions are bound by the operand stream into LDS -- 28 KB per tap round of a CU at the ~21 B/clk the LDS-DMA path
+// sustains IS their 66-69 us -- and that stream is mostly weights, whose bytes per MFMA fall with the
+// PIXELS a staged weight tile serves.  Here one 10 KB weight tile serves 256 pixels (154 B of staging per MFMA instead of 290), and
+// N = 320 at the bench batch is 128 pixel tiles x 2 channel tiles = 256 workgroups: one per CU, no tail.  78 KB of LDS.
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -23,24 +29,31 @@
 
 namespace {
 
-constexpr int T3H = 8, T3W = 16;
-constexpr int P3W = T3W + 2, P3H = T3H + 2;
-constexpr int NPIX3 = P3H * P3W;               // 180 patch pixels
+constexpr int T3W = 16, P3W = T3W + 2;
 constexpr int CK3 = 32;
 constexpr int BN3 = 160;
-constexpr int AB3 = 12 * 1024;                 // 180 rows x 64 B = 11.25 pieces -> 12 (three per wave; rows past 179 are never read)
 constexpr int WB3 = BN3 * 64, NWR3 = 3;        // 10 pieces per tap
-constexpr int PATCH3_LDS = 2 * AB3 + NWR3 * WB3;      // 55,296
 constexpr int CLD3 = BN3 + 4;
 constexpr int EROWS3 = 64;
-static_assert(PATCH3_LDS >= EROWS3 * CLD3 * 4, "the epilogue tile must fit the main-loop LDS");
+template <int NW> struct T3 {
+    static constexpr int TH = 2 * NW;                          // pixel rows of the tile: two per wave
+    static constexpr int NPIX = (TH + 2) * P3W;                // 180 | 324 patch pixels
+    static constexpr int APIECES = 3 * NW;                     // one-KB patch pieces staged per chunk (three per wave): 12 | 24 >= NPIX / 16
+    static constexpr int AB = APIECES * 1024;
+    static constexpr int WPW = (10 + NW - 1) / NW;             // weight pieces per wave and tap: 3 | 2 (waves that run out re-fetch piece 9)
+    static constexpr int LDS = 2 * AB + NWR3 * WB3;            // 55,296 | 79,872
+    static_assert(APIECES * 16 >= NPIX, "the patch must fit its pieces");
+    static_assert(LDS >= EROWS3 * CLD3 * 4, "the epilogue tile must fit the main-loop LDS");
+};
 // MFMA column (lane & 31) -> pixel of a 2 x 16 pixel block: conv_patch.hip's permutation (conflict-free ds_read_b128 groups)
 __device__ constexpr unsigned char kColPix3[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7,
                                                    30, 31, 16, 17, 22, 23, 24, 25, 26, 27, 28, 29, 18, 19, 20, 21};
 
-template <bool F16>
-__global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmParams p) {
+template <bool F16, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv3x3_patch3_kernel(const ConvGemmParams p) {
     using E = El<F16>;
+    using T = T3<NW>;
+    constexpr int T3H = T::TH, NPIX3 = T::NPIX, AB3 = T::AB, WPW = T::WPW, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -69,8 +82,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmPa
     const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
     const v4i_t dx = raw_rsrc(p.x, p.x_bytes), dw = raw_rsrc(p.w, p.w_bytes);
     constexpr uint32_t FAR = 0x80000000u;      // out of range, and still out of range after the loop's running adds (operands < 2 GiB)
-    uint32_t acur[3], wcur[3];                 // running source offsets: patch pieces of the NEXT chunk to stage, weight pieces of the next tap
-    uint32_t adst[3], wdst[3];                 // LDS byte addresses of the pieces inside patch buffer 0 / ring slot 0 (wave-uniform)
+    uint32_t acur[3], wcur[WPW];               // running source offsets: patch pieces of the NEXT chunk to stage, weight pieces of the next tap
+    uint32_t adst[3], wdst[WPW];               // LDS byte addresses of the pieces inside patch buffer 0 / ring slot 0 (wave-uniform)
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int slot = (wv * 3 + i) * 64 + lane, pp = slot >> 2, piece = (slot & 3) ^ ((pp >> 2) & 3);
@@ -84,11 +97,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmPa
         }
         adst[i] = smem_base + (uint32_t)((wv * 3 + i) * 1024);
     }
-    // ten weight pieces per tap over four waves: wave w issues pieces w, w + 4 and min(w + 8, 9) -- waves 2 and 3 re-fetch piece 9 (the same
-    // bytes to the same place, a benign duplicate), so that every wave issues exactly three pieces per tap and the counted waits are uniform
+    // ten weight pieces per tap over NW waves: wave w issues pieces w, w + NW ... clamped to 9 -- a wave that runs out re-fetches piece 9 (the
+    // same bytes to the same place, a benign duplicate), so that every wave issues exactly WPW pieces per tap and the counted waits are uniform
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int pc = min(wv + 4 * i, 9);
+    for (int i = 0; i < WPW; ++i) {
+        const int pc = min(wv + NW * i, 9);
         const int slot = pc * 64 + lane, row = slot >> 2, piece = (slot & 3) ^ ((row >> 2) & 3);
         wcur[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8 + c_begin * CK3) * 2) : FAR;
         wdst[i] = smem_base + (uint32_t)(2 * AB3 + pc * 1024);
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmPa
     };
     auto dma_w = [&](auto ring_c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < WPW; ++i) {
             asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
                          : : "v"(wcur[i]), "s"(wdst[i]), "s"(dw), "n"(decltype(ring_c)::value * WB3) : "memory", "scc");
             wcur[i] += w_tap;
@@ -145,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmPa
             if (t % 3 == 0) dma_w(i2); else if (t % 3 == 1) dma_w(i0); else dma_w(i1);
             if (t == 6) {                              // (the tap just staged was tap 8: the next one is tap 0 of the next chunk)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) wcur[i] += w_chunk - w_tap;
+                for (int i = 0; i < WPW; ++i) wcur[i] += w_chunk - w_tap;
             }
             if (t == 5) dma_patch(std::integral_constant<int, AB ^ 1>{});          // (always 3 pieces: the counted waits rely on it)
             const char* Ws = smem + 2 * AB3 + (t % 3) * WB3;
@@ -158,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmPa
 #pragma unroll
                 for (int a = 0; a < 5; ++a) acc[a] = E::mfma(wf[a], xf, acc[a]);
             }
-            // the next tap's weight pieces have landed: everything but this tap's three pieces (and, at taps 5 and 6, the three patch
+            // the next tap's weight pieces have landed: everything but this tap's WPW pieces (and, at taps 5 and 6, the three patch
             // pieces issued behind them at tap 5) may stay in flight
-            if (t == 5 || t == 6) dma_wait_keep_n<6>(); else dma_wait_keep_n<3>();
+            if (t == 5 || t == 6) dma_wait_keep_n<WPW + 3>(); else dma_wait_keep_n<WPW>();
             __syncthreads();
         }
     };
@@ -172,14 +185,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmPa
     dma_wait();                  // pieces staged past the end are still landing: the epilogue reuses this LDS
     __syncthreads();
 
-    // ---- epilogue (conv_gemm.hip's scheme): 64 pixels (two waves) at a time through LDS, 8 consecutive channels per thread ----
+    // ---- epilogue (conv_gemm.hip's scheme): 64 pixels (two waves) at a time through LDS, 8 consecutive channels per thread.  A thread keeps
+    // ONE 8-channel column (tid % 20) for every pixel row it emits (row lanes tid / 20; the last NT % 20 threads idle), so that the
+    // GroupNorm statistics of the output (gn_stats_out, as in conv_patch.hip) accumulate in registers: per-tile, per-group fp32
+    // (sum, sum of squares) of the ROUNDED values, folded in a fixed order ----
     float* Cs = reinterpret_cast<float*>(smem);
     constexpr int CPR = BN3 / 8;                   // 20 chunks per pixel row
-    constexpr int CHUNKS = EROWS3 * CPR;           // 1280
+    constexpr int RL = NT / CPR;                   // 12 | 25 row lanes
     const int HW = H * W;
     float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)split * p.M * p.N : nullptr;
-#pragma unroll 1
-    for (int wr = 0; wr < 2; ++wr) {
+    const int e_col = tid % CPR, e_rl = tid / CPR;
+    const int n = n0 + e_col * 8;
+    const bool want_stats = p.gn_stats_out != nullptr && slab == nullptr;
+    const int cpg = want_stats ? p.N / p.gn_stats_groups : 1;
+    const int st_split = min(8, (n / cpg + 1) * cpg - n);       // channels [0, split) of the chunk -> its first group
+    float st[4] = {0.f, 0.f, 0.f, 0.f};
+    // everything the epilogue reads from memory is requested NOW, in one burst (one workgroup per CU at NW = 8: nothing else is resident to
+    // hide a load issued inside the loop): bias + per-batch vector of the thread's column once, the residual of every row it will emit
+    constexpr int RPT = (EROWS3 + RL - 1) / RL;    // rows per thread and pass: 6 | 3
+    const bool mine = e_rl < RL && n < p.N;
+    const int nv = (n + 8 <= p.N) ? 8 : 4;
+    float4 pre0 = make_float4(0, 0, 0, 0), pre1 = pre0;
+    const bool use_pre = mine && slab == nullptr && (p.bias != nullptr || p.rowvec != nullptr);
+    if (use_pre) load_col_addends(p, p.rowvec ? b : -1, n, nv, pre0, pre1);
+    uint4 rres[NW / 2][RPT];
+    const bool use_rpre = mine && slab == nullptr && p.res != nullptr;
+    if (use_rpre) {
+#pragma unroll
+        for (int wr = 0; wr < NW / 2; ++wr)
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int row = e_rl + k * RL, q = wr * EROWS3 + row;
+                const int oy = y0 + q / T3W, ox = x0 + q % T3W;
+                rres[wr][k] = make_uint4(0, 0, 0, 0);
+                if (row < EROWS3 && oy < H && ox < W) {
+                    const bf16_t* rp = p.res + (size_t)((b * H + oy) * W + ox) * p.res_ld + n;
+                    if (nv == 8) rres[wr][k] = *reinterpret_cast<const uint4*>(rp);
+                    else { const uint2 t2 = *reinterpret_cast<const uint2*>(rp); rres[wr][k].x = t2.x; rres[wr][k].y = t2.y; }
+                }
+            }
+    }
+#pragma unroll
+    for (int wr = 0; wr < NW / 2; ++wr) {
         if ((wave >> 1) == wr) {
             const int row_l = (wave & 1) * 32 + cpix;
 #pragma unroll
@@ -190,52 +237,103 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch3_kernel(const ConvGemmPa
                         make_float4(acc[a][4 * j], acc[a][4 * j + 1], acc[a][4 * j + 2], acc[a][4 * j + 3]);
         }
         __syncthreads();
-        for (int ch = tid; ch < CHUNKS; ch += 256) {
-            const int row = ch / CPR, cc8 = (ch - row * CPR) * 8;
-            const int q = wr * EROWS3 + row;
-            const int oy = y0 + q / T3W, ox = x0 + q % T3W;
-            const int n = n0 + cc8;
-            if (n >= p.N || oy >= H || ox >= W) continue;
-            const int m = (b * H + oy) * W + ox;
-            const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD3 + cc8);
-            const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD3 + cc8 + 4);
-            if (slab) {
-                slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, false);
-            } else {
-                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HW);
+        if (mine) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int row = e_rl + k * RL;
+                if (row >= EROWS3) continue;
+                const int q = wr * EROWS3 + row;
+                const int oy = y0 + q / T3W, ox = x0 + q % T3W;
+                if (oy >= H || ox >= W) continue;
+                const int m = (b * H + oy) * W + ox;
+                const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD3 + e_col * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD3 + e_col * 8 + 4);
+                if (slab) {
+                    slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, false);
+                } else {
+                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    epilogue8<F16>(p, v, m, n, nv, HW, use_pre, pre0, pre1, use_rpre, rres[wr][k]);
+                    if (want_stats) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (e < nv) {
+                                const float r = E::tof(E::fromf(v[e]));           // statistics of the STORED tensor
+                                if (e < st_split) { st[0] += r; st[1] += r * r; } else { st[2] += r; st[3] += r * r; }
+                            }
+                        }
+                    }
+                }
             }
         }
-        if (wr == 0) __syncthreads();
+        if (wr + 1 < NW / 2) __syncthreads();
+    }
+    if (want_stats) {
+        __syncthreads();                        // the fp32 tile in LDS is dead: reuse its head for the NT x 4 partials
+        float* red = reinterpret_cast<float*>(smem);
+        *reinterpret_cast<float4*>(red + tid * 4) = make_float4(st[0], st[1], st[2], st[3]);
+        __syncthreads();
+        const int G = p.gn_stats_groups;
+        if (tid < G) {                          // fixed summation order: column chunk, then row lane (deterministic)
+            const int g = tid;
+            float S = 0.f, Q = 0.f;
+            for (int j = 0; j < CPR; ++j) {
+                const int nj = n0 + 8 * j;
+                if (nj >= p.N) break;
+                const int gj = nj / cpg;
+                if (gj == g || gj + 1 == g) {
+                    const int o = (gj == g) ? 0 : 2;
+                    for (int rl = 0; rl < RL; ++rl) { S += red[(j + CPR * rl) * 4 + o]; Q += red[(j + CPR * rl) * 4 + o + 1]; }
+                }
+            }
+            const int nparts = tiles_y * tiles_x * n_tiles;
+            const int part = (ty * tiles_x + tx) * n_tiles + tile_n;
+            float* dst = p.gn_stats_out + (((size_t)b * nparts + part) * G + g) * 2;
+            dst[0] = S; dst[1] = Q;
+        }
     }
 }
 
 }  // namespace
 
-bool imd_conv_patch3_supported(const ConvGemmParams& p) {
+static bool patch3_geometry(const ConvGemmParams& p, int th) {
     const bool geom = p.ups ? (p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win) : (p.Hin == p.Hout && p.Win == p.Wout);
-    return p.taps == 9 && p.stride == 1 && !p.pad_br_only && geom && p.Hout >= T3H && p.Wout >= T3W && (p.Cin % CK3) == 0 &&
+    return p.taps == 9 && p.stride == 1 && !p.pad_br_only && geom && p.Hout >= th && p.Wout >= T3W && (p.Cin % CK3) == 0 &&
            p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU && p.gn_a == nullptr && (p.x_pix_stride % 8) == 0 &&
            p.x_bytes < 0x80000000u && p.w_bytes < 0x80000000u;
 }
+bool imd_conv_patch3_supported(const ConvGemmParams& p) { return patch3_geometry(p, T3<4>::TH); }       // tile config 22
+bool imd_conv_patch4_supported(const ConvGemmParams& p) { return patch3_geometry(p, T3<8>::TH); }       // tile config 23 (16 x 16 pixel tiles)
 
-int imd_launch_conv_patch3(const ConvGemmParams& p_in, hipStream_t s) {
+template <int NW>
+static int launch_patch3(const ConvGemmParams& p_in, hipStream_t s, const char* what) {
     ConvGemmParams p = p_in;
     p.splitk_counters = nullptr;            // (K slices always finish with the shared second launch)
-    p.gn_stats_out = nullptr;               // (un-split statistics come from conv_patch.hip's epilogue only; validated by the dispatcher)
-    if (!imd_conv_patch3_supported(p))
-        return imd_set_error("conv_patch3: unsupported geometry (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 32 == 0, row-major output, operands < 2 GiB)");
+    if (p.split_k > 1) p.gn_stats_out = nullptr;      // (K slices: the statistics come from the finish launch; the dispatcher validated the request)
+    if (!patch3_geometry(p, T3<NW>::TH))
+        return imd_set_error("%s: unsupported geometry (needs 3x3 stride 1, H >= %d, W >= 16, Cin %% 32 == 0, row-major output, operands < 2 GiB)", what, T3<NW>::TH);
     static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
-    const kern_t kern = h ? conv3x3_patch3_kernel<true> : conv3x3_patch3_kernel<false>;
+    const kern_t kern = h ? conv3x3_patch3_kernel<true, NW> : conv3x3_patch3_kernel<false, NW>;
     if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PATCH3_LDS);
-        if (e != hipSuccess) return imd_set_error("conv_patch3: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T3<NW>::LDS);
+        if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
         attr_set[h] = true;
     }
     const int B = p.M / (p.Hout * p.Wout);
-    const long blocks = (long)B * ((p.Hout + T3H - 1) / T3H) * ((p.Wout + T3W - 1) / T3W) * ((p.N + BN3 - 1) / BN3);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH3_LDS, s, p);
-    return imd_check_launch("conv_patch3");
+    const long blocks = (long)B * ((p.Hout + T3<NW>::TH - 1) / T3<NW>::TH) * ((p.Wout + T3W - 1) / T3W) * ((p.N + BN3 - 1) / BN3);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(NW * 64), T3<NW>::LDS, s, p);
+    return imd_check_launch(what);
 }
+
+// statistic partials per image written through gn_stats_out by the un-split launch of tile config 22 (nw = 4) / 23 (nw = 8); 0: cannot
+int imd_conv_patch3_stats_parts_of(const ConvGemmParams& p, int nw) {
+    const int th = nw == 8 ? T3<8>::TH : T3<4>::TH;
+    if (!patch3_geometry(p, th) || p.split_k > 1 || p.out_f32 || p.gn_stats_groups <= 0 || p.gn_stats_groups > 64 || p.N % p.gn_stats_groups ||
+        (p.N / p.gn_stats_groups) < 8 || (p.N % 8))
+        return 0;
+    return ((p.Hout + th - 1) / th) * ((p.Wout + T3W - 1) / T3W) * ((p.N + BN3 - 1) / BN3);
+}
+
+int imd_launch_conv_patch3(const ConvGemmParams& p, hipStream_t s) { return launch_patch3<4>(p, s, "conv_patch3"); }
+int imd_launch_conv_patch4(const ConvGemmParams& p, hipStream_t s) { return launch_patch3<8>(p, s, "conv_patch3 (16 x 16 pixel tiles)"); }

@@ -79,9 +79,12 @@ __device__ __forceinline__ void load_col_addends(const ConvGemmParams& p, int bi
 // row-major chunk loop a thread keeps the same 8 columns for every row it emits, so the tile kernels hoist these loads out
 // of the loop (isolated 320 -> 2560 projection: 123 -> 117 us; neutral end to end).  The values travel BY VALUE: handing
 // epilogue8 a pointer to a caller-side array demoted that array to scratch memory (48 B/lane) and cost 2.4 % end to end.
+// use_rpre / rpre: the 8 residual values of this chunk fetched by the caller AHEAD of the epilogue loop (the one-workgroup-per-CU tile
+// kernels have nothing else resident to hide the residual's latency behind: conv_patch3.hip fetches all of a thread's rows at once)
 template <bool F16>
 __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int m, int n, int nv, int HWo, bool use_pre = false,
-                                          float4 pre0 = float4{0, 0, 0, 0}, float4 pre1 = float4{0, 0, 0, 0}) {
+                                          float4 pre0 = float4{0, 0, 0, 0}, float4 pre1 = float4{0, 0, 0, 0}, bool use_rpre = false,
+                                          uint4 rpre = uint4{0, 0, 0, 0}) {
     using E = El<F16>;
     const int bi = m / HWo;
     float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, r0 = b0, r1 = b0;
@@ -91,9 +94,12 @@ __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int
     if (use_pre) { b0 = pre0; b1 = pre1; }          // (by value: a pointer to a caller-side array would push it into scratch)
     else load_col_addends(p, bi, n, nv, b0, b1);
     if (p.res) {
-        const bf16_t* rp = p.res + (size_t)m * p.res_ld + n;
-        if (full) rr = *reinterpret_cast<const uint4*>(rp);
-        else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rr.x = t.x; rr.y = t.y; }
+        if (use_rpre) rr = rpre;
+        else {
+            const bf16_t* rp = p.res + (size_t)m * p.res_ld + n;
+            if (full) rr = *reinterpret_cast<const uint4*>(rp);
+            else { const uint2 t = *reinterpret_cast<const uint2*>(rp); rr.x = t.x; rr.y = t.y; }
+        }
     }
     v[0] += b0.x + r0.x; v[1] += b0.y + r0.y; v[2] += b0.z + r0.z; v[3] += b0.w + r0.w;
     v[4] += b1.x + r1.x; v[5] += b1.y + r1.y; v[6] += b1.z + r1.z; v[7] += b1.w + r1.w;

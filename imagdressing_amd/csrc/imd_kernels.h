@@ -29,6 +29,9 @@ bool imd_conv_patch2_supported(const ConvGemmParams& p);      // conv_patch2.hip
 int imd_launch_conv_patch2(const ConvGemmParams& p, hipStream_t s);
 bool imd_conv_patch3_supported(const ConvGemmParams& p);      // conv_patch3.hip: 8 x 16 pixels x 160 channels (tile config 22)
 int imd_launch_conv_patch3(const ConvGemmParams& p, hipStream_t s);
+bool imd_conv_patch4_supported(const ConvGemmParams& p);      // conv_patch3.hip with eight waves: 16 x 16 pixels x 160 channels (tile config 23)
+int imd_launch_conv_patch4(const ConvGemmParams& p, hipStream_t s);
+int imd_conv_patch3_stats_parts_of(const ConvGemmParams& p, int nw);
 int imd_conv_patch_stats_parts_of(const ConvGemmParams& p);
 int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p, int cfg);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);

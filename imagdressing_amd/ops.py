@@ -148,6 +148,7 @@ FUSED_GN_STATS = _os.environ.get("IMD_FUSED_GN_STATS", "1") != "0"   # 3x3 convs
 CFG_PAIR_DEDUP = _os.environ.get("IMD_CFG_PAIR_DEDUP", "1") != "0"   # sampling loop: conv_in + first resnet once for the two identical CFG halves (A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
+GEMM_EVENT_HOOK = None     # tools/insitu_conv.py sets this to a dict: every conv_gemm launch is bracketed by HIP events, keyed by (shape key, cfg, split)
 _GEMM_TABLE = None
 
 
@@ -265,6 +266,8 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg == 22 and not lib.imd_conv_patch3_supported(C.byref(p)):
                 cfg, split_k = -1, 0
+            if cfg == 23 and not lib.imd_conv_patch4_supported(C.byref(p)):
+                cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
     if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and Wout >= PATCH_MIN_W and N >= 64 \
@@ -278,7 +281,7 @@ def conv_gemm(
         if SPLITK_IN_KERNEL:
             p.splitk_counters = splitk_counters(x.device).data_ptr()
     stats = None
-    if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and (cfg == 5 or split_k > 1):
+    if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and (cfg in (5, 22, 23) or split_k > 1):
         p.gn_stats_groups = gn_stats_groups
         nparts = lib.imd_conv_gemm_stats_parts(C.byref(p), cfg)       # halo-patch epilogue (un-split) or the finish launch of the K slices
         if nparts > 0:
@@ -287,7 +290,14 @@ def conv_gemm(
             p.gn_stats_out = stats[0].data_ptr()
         else:
             p.gn_stats_groups = 0
-    L.check(lib.imd_conv_gemm(C.byref(p), cfg, _stream()))
+    if GEMM_EVENT_HOOK is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.imd_conv_gemm(C.byref(p), cfg, _stream()))
+        e1.record()
+        GEMM_EVENT_HOOK.setdefault((f"{M},{N},{K},{taps},{stride},{int(ups)}|{Hout}x{Wout}", cfg, split_k), []).append((e0, e1))
+    else:
+        L.check(lib.imd_conv_gemm(C.byref(p), cfg, _stream()))
     if stats is not None:
         out._imd_gn_stats = stats
     return out

@@ -79,7 +79,7 @@ typedef struct imd_conv_gemm_params {
     int* splitk_counters; /* split_k > 1 only.  NULL: the K slices are summed by a second launch (fixed order).  Otherwise >=
                           * IMD_SPLITK_COUNTERS ints that are ZERO on entry and are left zero: every output tile's last-arriving
                           * workgroup sums the slices itself, in the same fixed order (bit-identical results, one launch less) */
-    /* GroupNorm statistics of the OUTPUT produced in the epilogue (cfg 5 with split_k == 1, or the finish launch of a K-sliced problem:
+    /* GroupNorm statistics of the OUTPUT produced in the epilogue (cfg 5 / 22 / 23 with split_k == 1, or the finish launch of a K-sliced problem:
      * imd_conv_gemm_stats_parts(); row-major 16-bit output, N % gn_stats_groups == 0): every workgroup writes the fp32 (sum, sum of squares) of its tile's final values per group to
      * gn_stats_out[((b * nparts + part) * G + g) * 2], part = (pixel tile of the image) * n_tiles + channel tile, nparts =
      * imd_conv_patch_stats_parts(); groups outside the tile get zeros.  The next imd_groupnorm on that tensor passes the buffer
@@ -205,7 +205,8 @@ int imd_device_check(int device);
  * 18: the gathering form of 17 for 3x3 convolutions (stride 1 | 2, Cin % 32 == 0; K slices allowed for 17 and 18);
  * 19 / 20: 17 / 18 with a four-stage ring (64 KB, two workgroups per CU, three tiles of lead);
  * 21: the halo-patch kernel with 16 x 16 pixel tiles (256 pixels x 128 channels per workgroup, wave tiles 128 x 64: half the weight bytes per MAC);
- * 22: the halo-patch kernel with 8 x 16 pixels x 160 channels per workgroup (wave tiles 32 x 160: N = 320 k runs without idle waves or padded MFMAs).
+ * 22: the halo-patch kernel with 8 x 16 pixels x 160 channels per workgroup (wave tiles 32 x 160: N = 320 k runs without idle waves or padded MFMAs);
+ * 23: 22 with eight waves = 16 x 16 pixels x 160 channels per workgroup (one staged weight tile serves 256 pixels: 154 instead of 290 bytes of LDS-DMA per MFMA).
  * Results are identical up to fp32 summation order. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);
@@ -257,11 +258,14 @@ int imd_conv_patch_supported(const imd_conv_gemm_params* p);
 int imd_conv_patch2_supported(const imd_conv_gemm_params* p);
 /* 1 iff tile config 22 (the halo-patch kernel with 160-channel tiles, conv_patch3.hip: N = 320 k without idle waves) takes this geometry */
 int imd_conv_patch3_supported(const imd_conv_gemm_params* p);
+/* 1 iff tile config 23 (the same kernel with eight waves: 16 x 16 pixels x 160 channels per workgroup) takes this geometry */
+int imd_conv_patch4_supported(const imd_conv_gemm_params* p);
 /* number of statistic partials per image the halo-patch kernel writes for this geometry (gn_stats_out), 0 if it cannot */
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p);
 /* the same for ANY launch: partials per image that imd_conv_gemm(p, cfg) writes through gn_stats_out -- the halo-patch epilogue (cfg 5, no K
  * slices) or, with p->split_k > 1 and a separate finish launch (splitk_counters == NULL), the finish launch itself, which then sums the
- * slices, runs the epilogue AND emits the statistics of the tensor it stores (row-major 16-bit outputs, N / groups >= 8); 0: none */
+ * slices, runs the epilogue AND emits the statistics of the tensor it stores (row-major 16-bit outputs, N / groups >= 8); the halo-patch
+ * kernels with 160-channel tiles (cfg 22 / 23) emit them from their own epilogue like cfg 5; 0: none */
 int imd_conv_gemm_stats_parts(const imd_conv_gemm_params* p, int cfg);
 /* 1 iff tile config 16 (256 x 256 x 64 LDS-DMA tile kernel, gemm_dma.hip: plain linear layer, K % 64 == 0, no K split) can run *p. */
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p);

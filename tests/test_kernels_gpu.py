@@ -480,9 +480,10 @@ def test_conv3x3_halo_patch_256_pixel_tiles(ops, B, H, W, Cin, Cout, split, ups,
     # ragged maps (tiles hang over the right / bottom edge) and the fused nearest-2x upsample (H, W = the STORED map)
     (1, 96, 72, 320, 320, 1, False), (2, 48, 36, 640, 640, 2, False), (1, 17, 19, 32, 40, 1, False),
     (1, 8, 8, 64, 320, 1, True), (2, 16, 16, 640, 640, 2, True), (1, 12, 18, 32, 200, 1, True)])
+@pytest.mark.parametrize("cfg", [22, 23])
 @DTS
-def test_conv3x3_halo_patch_160_channel_tiles(ops, B, H, W, Cin, Cout, split, ups, dt):
-    """tile config 22 (conv_patch3.hip: 8 x 16 pixels x 160 channels per workgroup, wave tiles 32 x 160) == F.conv2d with the full
+def test_conv3x3_halo_patch_160_channel_tiles(ops, B, H, W, Cin, Cout, split, ups, cfg, dt):
+    """tile configs 22 / 23 (conv_patch3.hip: 8 x 16 | 16 x 16 pixels x 160 channels per workgroup, wave tiles 32 x 160) == F.conv2d with the full
     epilogue, K slices, ragged maps, channel counts that are not multiples of 160 and the fused upsample; bit-identical to the
     128-channel-tile kernel (same K order and MFMA sequence per output element)"""
     x = rnd(1, B, Cin, H, W).to(dt)
@@ -493,17 +494,21 @@ def test_conv3x3_halo_patch_160_channel_tiles(ops, B, H, W, Cin, Cout, split, up
     ref = F.conv2d(xin, w.float(), b, padding=1).permute(0, 2, 3, 1) + temb[:, None, None, :] + res.float()
     xd = dev(x.permute(0, 2, 3, 1).contiguous())
     kw = dict(rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), ups=ups, split_k=split)
-    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=22, **kw)
+    if cfg == 23 and Ho < 16:
+        with pytest.raises(ops.L.ImdError):
+            ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=23, **kw)
+        return
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=cfg, **kw)
     assert tuple(out.shape) == (B, Ho, Wo, Cout)
-    assert_close(out, ref, what=f"160-channel halo-patch conv split={split} ups={ups}")
+    assert_close(out, ref, what=f"160-channel halo-patch conv cfg={cfg} split={split} ups={ups}")
     assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=5, **kw)), "differs from the 128-channel tile kernel"
     if split > 1:         # K slices: the finish launch can emit the GroupNorm statistics for this tile config as well
         G = 4 if Cout % 32 else 32
         if Cout % G == 0 and Cout // G >= 8:
-            st_out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=22, gn_stats_groups=G, **kw)
+            st_out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=cfg, gn_stats_groups=G, **kw)
             assert torch.equal(st_out, out) and getattr(st_out, "_imd_gn_stats", None) is not None
     with pytest.raises(ops.L.ImdError):
-        ops.conv2d_nhwc(dev(rnd(1, 1, 8, 8, 32).to(dt)), dev(rnd(2, 32, 288).to(dt)), None, cfg=22)        # W < 16
+        ops.conv2d_nhwc(dev(rnd(1, 1, 8, 8, 32).to(dt)), dev(rnd(2, 32, 288).to(dt)), None, cfg=cfg)        # W < 16
 
 
 @pytest.mark.parametrize("silu", [False, True])
@@ -530,8 +535,9 @@ def test_conv3x3_fused_groupnorm(ops, B, H, W, Cin, Cout, silu, dt):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,G", [(2, 32, 32, 320, 320, 32), (1, 16, 32, 64, 640, 32), (1, 24, 40, 64, 320, 32), (2, 16, 16, 96, 128, 8),
                                                (1, 64, 64, 32, 1280, 32)])
+@pytest.mark.parametrize("cfg", [5, 22, 23])
 @DTS
-def test_conv3x3_epilogue_groupnorm_statistics(ops, B, H, W, Cin, Cout, G, dt):
+def test_conv3x3_epilogue_groupnorm_statistics(ops, B, H, W, Cin, Cout, G, cfg, dt):
     """The halo-patch conv's epilogue emits the GroupNorm statistics of its OUTPUT (bias, time-embedding vector and residual
     applied; groups that straddle 128-channel tiles, ragged pixel tiles): folded, they equal the statistics of the output tensor,
     and the next group_norm of that tensor -- which then skips its own statistics pass -- equals F.group_norm."""
@@ -540,8 +546,9 @@ def test_conv3x3_epilogue_groupnorm_statistics(ops, B, H, W, Cin, Cout, G, dt):
     b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, H, W, Cout).to(dt)
     gamma = 1.0 + 0.2 * rnd(6, Cout); beta = 0.2 * rnd(7, Cout)
     xd = dev(x.permute(0, 2, 3, 1).contiguous())
-    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), cfg=5, split_k=1,
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), cfg=cfg, split_k=1,
                           gn_stats_groups=G)
+    assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), cfg=5, split_k=1))
     st = getattr(out, "_imd_gn_stats", None)
     assert st is not None and st[2] == G, "the halo-patch kernel must hand its statistics on"
     part, nparts, _ = st

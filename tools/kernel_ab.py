@@ -20,7 +20,7 @@ LINEARS = [  # (name, M, N, K, geglu)
 ]
 ap = argparse.ArgumentParser()
 ap.add_argument("--what", default="conv"); ap.add_argument("--cfg", type=int, default=-2); ap.add_argument("--dtype", default="bf16")
-ap.add_argument("--iters", type=int, default=30); ap.add_argument("--tag", default=os.environ.get("IMD_LIB_PATH", "cur").split("_")[-1].replace(".so", ""))
+ap.add_argument("--iters", type=int, default=30); ap.add_argument("--epi", action="store_true", help="conv: the ResNet epilogue -- time-embedding vector, residual, GroupNorm statistics of the output"); ap.add_argument("--tag", default=os.environ.get("IMD_LIB_PATH", "cur").split("_")[-1].replace(".so", ""))
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 
@@ -41,7 +41,10 @@ if a.what == "conv":
         xs = [torch.randn(B, H, W, Cin, device="cuda").to(dt) for _ in range(4)]
         ws = [(torch.randn(Cout, 9 * Cin, device="cuda") * (9 * Cin) ** -0.5).to(dt) for _ in range(4)]
         b = torch.randn(Cout, device="cuda")
-        us = timed(lambda i: ops.conv2d_nhwc(xs[i % 4], ws[i % 4], b, cfg=cfg, split_k=sk), a.iters)
+        kw = {}
+        if a.epi:
+            kw = dict(rowvec=torch.randn(B, Cout, device="cuda"), rowvec_stride=Cout, res=torch.randn(B, H, W, Cout, device="cuda").to(dt), gn_stats_groups=32)
+        us = timed(lambda i: ops.conv2d_nhwc(xs[i % 4], ws[i % 4], b, cfg=cfg, split_k=sk, **kw), a.iters)
         print(json.dumps(dict(lib=a.tag, shape=name, cfg=cfg, us=round(us, 1), tflops=round(2.0 * B * H * W * Cout * 9 * Cin / us / 1e6, 1))), flush=True)
 else:
     cfg = 17 if a.cfg == -2 else a.cfg
