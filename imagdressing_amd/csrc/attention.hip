@@ -443,7 +443,11 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 // head-dim-40 kernel variant (tuning knob 0, imd_set_tuning(0, v)); all variants give the same result up to fp32 order:
-//   10 (default): attention_d40.hip, software-pipelined steps with the MFMA / VALU interleave written out (N >= 512; shorter
+//   13 (default): 12 with the overflow test of the deferred maximum only on the first and last steps of a phase and a check of the
+//      softmax denominators when the phase is done (a workgroup that finds one not finite runs again as variant 12); bf16 only,
+//      fp16 operands and the fused out-projection run 12;  12: 10 with the main loop unrolled over the three ring slots
+//      (compile-time LDS addresses, three-instruction staging pieces) and the order inside every MFMA slot pinned;
+//   10 (the round-3 default): attention_d40.hip, software-pipelined steps with the MFMA / VALU interleave written out (N >= 512; shorter
 //      sequences and the causal mask fall through to variant 4 below), head-dim rows 32..40 of P.V on v_mfma_f32_16x16x32,
 //      K / V^T staged by LDS-DMA when the caller guarantees K's pad column (imd_attn_params.k_pad_one), through registers
 //      otherwise;  11: as 10, always through registers;  9 / 7: the round-2 kernel (P.V as two 32x32x16 row blocks) with the
@@ -453,7 +457,7 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 //   2: 2 query blocks per wave, 32-key softmax blocks, speculative exp (round-1 default)
 //   4: 1 query block per wave, 32-key blocks, speculative exp      3: 1 query block, 64-key blocks, exact max every block
 //   1: as 3 with speculative exp
-int g_attn_qw40 = 12;
+int g_attn_qw40 = 13;
 
 int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }

@@ -215,7 +215,7 @@ __device__ __forceinline__ void attn_out_proj(const AttnParams& p, int b, int ro
 //   the queries, i.e. every wave issues 2 instead of 3 LDS-DMA pieces per 64 keys (the DMA issue sequence costs ~15 % of the
 //   4-wave kernel: profiles/r3b_attn_ablations.jsonl) and there is one barrier domain per CU.  LDS-DMA staging only.
 template <bool F16, int THR, int VAR>
-__global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(const AttnParams p) {
+__device__ __attribute__((always_inline)) bool attn40_body(const AttnParams& p) {
     using E = El<F16>;
     constexpr bool DMA = (VAR & 128) != 0;
     constexpr bool TAIL = (VAR & 8192) != 0;
@@ -226,6 +226,7 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
     // plus one running-offset add.  The issue-mix probe (tools/probes/issue_mix_probe.hip) puts this kernel's step within 15 % of what its
     // MFMA + VALU + LDS + DMA mix costs in isolation; what is left above that is scalar / address bookkeeping like this.
     constexpr bool STAT = (VAR & 2097152) != 0;
+    constexpr bool UNCHK = (VAR & 4194304) != 0;          // (with STAT) interior steps without the overflow test: experiment, see variant 13
     static_assert(!STAT || ((VAR & 128) && (VAR & 8192) && !(VAR & 32768)), "the static-ring loop exists for the 4-wave LDS-DMA kernel with the 16x16x32 tail");
     static_assert(!PROJ || (TAIL && !(VAR & 32768)), "the fused out-projection lives in the 4-wave kernel with the 16x16x32 tail");
     constexpr int NW = (VAR & 32768) ? 8 : 4;              // waves per workgroup
@@ -315,17 +316,21 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     unsigned long long tm_slots = 0, tm_check = 0, tm_sync = 0, tm_loop = 0, tm_steps = 0;      // VAR & 4096 only
+    bool bad = false;               // UNCHK: a softmax denominator of this lane is not finite
     for (int ph = 0; ph < nph; ++ph) {
         f32x16 o[2][2];
         f32x4 ot[2][2];                 // TAIL: rows 32..47 of O^T, [query block][16-query half]; o[.][1] is unused then
         float m_ref[2] = {0.f, 0.f};
+        auto reset_state = [&]() __attribute__((always_inline)) {      // (once per phase; twice when an UNCHK phase has to be re-run checked)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            if (hi == QPAD_HI) qf[qb][QPAD_T].x &= 0xffff0000u;       // Q pad slot = -m_ref = 0
+            for (int qb = 0; qb < 2; ++qb) {
+                m_ref[qb] = 0.f;
+                if (hi == QPAD_HI) qf[qb][QPAD_T].x &= 0xffff0000u;       // Q pad slot = -m_ref = 0
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) o[qb][dt] = zero16;
-            ot[qb][0] = zero4; ot[qb][1] = zero4;
-        }
+                for (int dt = 0; dt < 2; ++dt) o[qb][dt] = zero16;
+                ot[qb][0] = zero4; ot[qb][1] = zero4;
+            }
+        };
         const int L = ph ? p.L2 : p.L1;
         const int LP = ph ? p.L2P : p.L1P;
         const int kvb = ph ? (b / p.kv2_bdiv) : (b / p.kv1_bdiv);
@@ -391,6 +396,7 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
         uint32_t sdst[NPIECE];       // LDS byte address of the piece inside ring slot 0
         uint32_t scur[NPIECE];       // source byte offset of the piece for the NEXT unit to stage (running; += sstr per unit)
         uint32_t sstr[NPIECE];
+        auto init_running = [&]() __attribute__((always_inline)) {
         if constexpr (STAT) {
 #pragma unroll
             for (int i = 0; i < NPIECE; ++i) {
@@ -412,6 +418,7 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
                 for (int c4 = 0; c4 < 4; ++c4) sdsc[i][c4] = isk ? ds_k[c4] : ds_v[c4];
             }
         }
+        };
         auto dma_static = [&](auto slot_c) __attribute__((always_inline)) {      // stage the next unit into ring slot `slot_c` (compile-time)
             constexpr int SLOT = decltype(slot_c)::value;
 #pragma unroll
@@ -437,10 +444,12 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
 
         f32x16 sa[2], sb[2];
         uint4 pa[2][2], pb[2][2];
+        auto reset_p = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-            for (int g = 0; g < 2; ++g) pb[qb][g] = make_uint4(0, 0, 0, 0);      // P of "block -1"
+                for (int g = 0; g < 2; ++g) pb[qb][g] = make_uint4(0, 0, 0, 0);      // P of "block -1"
+        };
 
         // ---- one 32-key step: S_n = QK^T(block j+1), O += V^T P^T(block j-1), P_c = exp2(S_c) (block j) ----
         // 14 MFMAs (fragment f = 0..2: K chunks -> S_n, f = 3..6: V^T (dt, g) -> O; two query blocks each), 16 "pairs" of
@@ -454,8 +463,11 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
         constexpr int NFR = TAIL ? PD + 1 : 3;
         uint4 fr[NFR];               // LDS fragment ring: fragment f of a step lives in fr[(R0 + f) % 3]  (TAIL: (R0T + f) % (PD + 1))
         auto step = [&](const char* Vs, auto second_c, int j, f32x16 (&sc)[2], f32x16 (&sn)[2], uint4 (&pc)[2][2],
-                        uint4 (&pp)[2][2]) __attribute__((always_inline)) {
+                        uint4 (&pp)[2][2], auto chk_c) __attribute__((always_inline)) {
             constexpr bool SECOND = decltype(second_c)::value;        // second step of a unit: K block kb = 1, V^T groups 2, 3
+            // CHK = false (UNCHK kernels, interior steps only): no packed-max tracking, no overflow / first / ragged-block test, no exact path --
+            // the caller guarantees a complete block j > 0 and checks the softmax denominators for overflow at the end of the phase
+            constexpr bool CHK = decltype(chk_c)::value;
             constexpr int KB = SECOND ? 1 : 0, G0 = SECOND ? 2 : 0, R0 = SECOND ? 1 : 0;
             const char* Ks = Vs + VBY;
             auto frag = [&](int f, int kb, int g0) -> uint4 {
@@ -527,17 +539,23 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
                         if (f2 <= 5) fr[(R0T + f2) % NFR] = fragT(f2, SECOND ? 1 : 0);
                         else if (!SECOND && f2 - 6 < PD) fr[(R0T + f2) % NFR] = fragT(f2 - 6, 1);
                     }
-                    mmaT(i);
+                    // STAT kernels pin the order INSIDE a slot as well (fragment read, exp2 pair, pack, max, lane swap, then the MFMA):
+                    // left to the compiler the order changes with unrelated code (r4: 1 % either way between builds)
+                    if (STAT) __builtin_amdgcn_sched_barrier(0);
+                    if (!STAT) mmaT(i);
                     exp_pair(i + 1);
+                    if (STAT) __builtin_amdgcn_sched_barrier(0);
                     cvt_pair(i);
-                    if ((i & 1) && !(VAR & 2048)) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
+                    if (STAT) __builtin_amdgcn_sched_barrier(0);
+                    if ((i & 1) && !(VAR & 2048) && CHK) mq[0] = pk_max3(mq[0], word(i - 1), word(i));
                     if (i >= 4 && i < 12) swapT(i - 4);
+                    if (STAT) { __builtin_amdgcn_sched_barrier(0); mmaT(i); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 exp_pair(15);
                 cvt_pair(14);
                 cvt_pair(15);
-                if (!(VAR & 2048)) mq[0] = pk_max3(mq[0], word(14), word(15));
+                if (!(VAR & 2048) && CHK) mq[0] = pk_max3(mq[0], word(14), word(15));
             } else if (VAR & 1) {
                 if (!SECOND) {       // (the second step's first two fragments were read during the first step's last slots)
                     fr[0] = frag(0, KB, G0);
@@ -572,6 +590,7 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
 #pragma unroll
                 for (int w = 0; w < 16; w += 2) mq[(w >> 3) & 1] = pk_max3(mq[(w >> 3) & 1], word(w), word(w + 1));
             }
+            if constexpr (CHK) {
             uint32_t mm = pk_max3(mq[0], mq[1], mq[1]);
             // pin the speculative exp2 / pack work in THIS basic block: without it hipcc sinks it below the `forced` test
             // (its results are dead on the exact path) and the MFMAs above lose the VALU work they are meant to hide
@@ -641,9 +660,13 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
                     }
                 }
             }
+            }       // CHK
             if (VAR & 4096) tm_steps += 1;
         };
 
+        {
+        reset_state(); reset_p(); init_running();
+        constexpr bool checked_run = !UNCHK;
         // ---- prologue: unit -1 (K block 0 in its second half) -> S_a = QK^T(block 0); unit 0 staged behind it ----
         if (DMA) {
             dma_unit(-1, 2);
@@ -680,24 +703,35 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
         int ring = 0;                                               // u % NRING
         unsigned long long t_loop0 = 0;
         if (VAR & 4096) t_loop0 = __builtin_amdgcn_s_memtime();
-        if constexpr (STAT) {
-            auto body = [&](auto slot_c, int u) __attribute__((always_inline)) {      // iteration u on ring slot u % 3 = slot_c (compile-time)
+        if (STAT && !(UNCHK && checked_run)) {
+            auto body = [&](auto slot_c, int u, auto chk_c) __attribute__((always_inline)) {      // iteration u on ring slot u % 3 = slot_c (compile-time)
                 constexpr int SLOT = decltype(slot_c)::value;
                 dma_static(std::integral_constant<int, (SLOT + 2) % 3>{});          // unit u + 2; its buffer was last read in iteration u - 1
                 const char* Vs = smem + SLOT * BUFB;
-                step(Vs, std::false_type{}, 2 * u, sa, sb, pa, pb);
-                step(Vs, std::true_type{}, 2 * u + 1, sb, sa, pb, pa);
+                step(Vs, std::false_type{}, 2 * u, sa, sb, pa, pb, chk_c);
+                step(Vs, std::true_type{}, 2 * u + 1, sb, sa, pb, pa, chk_c);
                 iteration_sync();
             };
+            const std::integral_constant<int, 0> c0{}; const std::integral_constant<int, 1> c1{}; const std::integral_constant<int, 2> c2{};
+            constexpr std::integral_constant<bool, !UNCHK> interior_chk{};          // UNCHK: interior iterations run without the per-step test
             int u = 0;
-            for (; u + 3 <= NUF; u += 3) {
-                body(std::integral_constant<int, 0>{}, u);
-                body(std::integral_constant<int, 1>{}, u + 1);
-                body(std::integral_constant<int, 2>{}, u + 2);
-            }
-            if (u < NUF) {
-                body(std::integral_constant<int, 0>{}, u); ++u; ring = 1;
-                if (u < NUF) { body(std::integral_constant<int, 1>{}, u); ++u; ring = 2; }
+            if constexpr (UNCHK) {
+                // iteration 0 (first block: forced exact path) and the last one to three (a ragged block may sit there) keep the checked step
+                if (NUF > 0) { body(c0, 0, std::true_type{}); u = 1; ring = 1; }
+                for (; u + 3 <= NUF - 1; u += 3) { body(c1, u, interior_chk); body(c2, u + 1, interior_chk); body(c0, u + 2, interior_chk); }
+                if (u < NUF) {
+                    body(c1, u, std::true_type{}); ++u; ring = 2;
+                    if (u < NUF) {
+                        body(c2, u, std::true_type{}); ++u; ring = 0;
+                        if (u < NUF) { body(c0, u, std::true_type{}); ++u; ring = 1; }
+                    }
+                }
+            } else {
+                for (; u + 3 <= NUF; u += 3) { body(c0, u, std::true_type{}); body(c1, u + 1, std::true_type{}); body(c2, u + 2, std::true_type{}); }
+                if (u < NUF) {
+                    body(c0, u, std::true_type{}); ++u; ring = 1;
+                    if (u < NUF) { body(c1, u, std::true_type{}); ++u; ring = 2; }
+                }
             }
         } else
         for (int u = 0; u < NUF; ++u) {
@@ -706,8 +740,8 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
             } else if (!(VAR & 16)) load_unit(u + 1);
             const char* Vs = smem + (DMA ? ring : (u & 1)) * BUFB;
             ring = ring == NRING - 1 ? 0 : ring + 1;
-            step(Vs, std::false_type{}, 2 * u, sa, sb, pa, pb);
-            step(Vs, std::true_type{}, 2 * u + 1, sb, sa, pb, pa);
+            step(Vs, std::false_type{}, 2 * u, sa, sb, pa, pb, std::true_type{});
+            step(Vs, std::true_type{}, 2 * u + 1, sb, sa, pb, pa, std::true_type{});
             if (!DMA && !(VAR & 16)) store_unit((u + 1) & 1);
             unsigned long long t_s = 0;
             if (VAR & 4096) t_s = __builtin_amdgcn_s_memtime();
@@ -744,13 +778,24 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
                 }
             };
             if (J & 1) {
-                step(Vs, std::false_type{}, J - 1, sa, sb, pa, pb);
+                step(Vs, std::false_type{}, J - 1, sa, sb, pa, pb, std::true_type{});
                 drain(2, pa);
             } else {
                 drain(0, pb);
             }
             dma_wait();               // pieces of units past the end are still landing: the next phase restages every buffer
             __syncthreads();
+        }
+        if constexpr (UNCHK) {
+            // row 40 of the tail accumulators (reg 0 of lanes 32..47) holds the denominators of this lane's queries: not finite, or so
+            // large (>= 2^100) that a numerator sum |P.v| <= denominator * max|v| may have left fp32's range
+            if (lane >= 32 && lane < 48) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq) bad |= (__float_as_uint(ot[qb][hq][0]) & 0x7f800000u) >= (227u << 23);
+            }
+        }
         }
 
         // ---- end of phase: normalise; phase 0 of a two-phase row is parked in LDS rounded to the element type (the
@@ -882,6 +927,22 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
         atomicAdd(dbg + 0, tm_loop); atomicAdd(dbg + 1, tm_slots); atomicAdd(dbg + 2, tm_check); atomicAdd(dbg + 3, tm_sync);
         atomicAdd(dbg + 4, tm_steps); atomicAdd(dbg + 5, 1ull);
     }
+    if constexpr (UNCHK) return __syncthreads_or((int)bad) != 0;      // (also: everybody is done with the LDS before a re-run restages it)
+    return false;
+}
+
+// UNCHK kernels run WITHOUT the per-step overflow test on interior steps (the deferred maximum stays the first block's: P = 2^(s - m_ref)
+// is unbounded above, which bf16's 8 exponent bits and the fp32 accumulators absorb up to 2^127).  The softmax denominators are checked
+// when a phase is done; should one of them not be finite, the whole workgroup runs again with the checked step on every block and
+// overwrites its output (exact, slow, never seen on real data).  The two runs share nothing but the kernel arguments, so the cold
+// checked body costs the hot one no registers (a retry loop around the phase did: 244 SGPR + 63 VGPR spills, +6 % time).
+template <bool F16, int THR, int VAR>
+__global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(const AttnParams p) {
+    if constexpr ((VAR & 4194304) != 0) {
+        if (attn40_body<F16, THR, VAR>(p)) attn40_body<F16, THR, VAR & ~4194304>(p);
+    } else {
+        attn40_body<F16, THR, VAR>(p);
+    }
 }
 
 template <bool F16, int THR, int VAR>
@@ -979,7 +1040,10 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
                 return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
             }
             [[fallthrough]];
-        case 12:            // round 4 (default): the LDS-DMA kernel with the main loop unrolled over the three ring slots -- compile-time LDS
+        case 13:            // round 4 (default): 12 without the per-step overflow test on interior steps; bf16 only (fp16's P = 2^(s - m_ref) overflows at 2^16: real data gets there)
+            if (p.proj_w == nullptr && p.k_pad_one && !h) return launch_attn40<false, 8, 1 | 128 | 8192 | 2097152 | 4194304>(p, s);
+            [[fallthrough]];
+        case 12:            // round 4: the LDS-DMA kernel with the main loop unrolled over the three ring slots -- compile-time LDS
         default:            // addresses, three-instruction staging pieces, no first / ragged-block test on interior steps
             if (p.proj_w == nullptr && p.k_pad_one)
                 return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 2097152>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 2097152>(p, s);

@@ -97,7 +97,7 @@ int imd_set_tuning(int knob, int value) {
 #ifdef IMD_ABLATIONS
             IMD_REQUIRE(value >= 1 && value <= 54, "set_tuning: attention variant for head dim 40 must be 1..54 (20..49: timing ablations, WRONG results; 50..54: correct but no faster)");
 #else
-            IMD_REQUIRE(value >= 1 && value <= 12, "set_tuning: attention variant for head dim 40 must be 1..12 (the timing ablations 20..49 and the measured no-gain variants 50..54 exist only in -DIMD_ABLATIONS builds)");
+            IMD_REQUIRE(value >= 1 && value <= 13, "set_tuning: attention variant for head dim 40 must be 1..13 (the timing ablations 20..49 and the measured no-gain variants 50..54 exist only in -DIMD_ABLATIONS builds)");
 #endif
             g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;

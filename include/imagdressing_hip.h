@@ -234,8 +234,10 @@ int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long coun
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
 /* performance knobs (results are identical for every accepted setting up to fp32 summation order).  knob 0: head-dim-40 attention
- * kernel variant (default 10: software-pipelined kernel of attention_d40.hip with the P.V tail on v_mfma_f32_16x16x32, LDS-DMA
- * staging when imd_attn_params.k_pad_one; 11: the same with register staging; 9 / 7: the round-2 kernel with the same two staging
+ * kernel variant (default 13: the static-ring kernel 12 with the deferred-maximum overflow test on a phase's first and last steps
+ * only and a workgroup-level re-run as 12 when a softmax denominator comes out non-finite -- bf16, fp16 runs 12; 12: the LDS-DMA
+ * kernel with compile-time ring addresses; 10: software-pipelined kernel of attention_d40.hip with the P.V tail on
+ * v_mfma_f32_16x16x32, LDS-DMA staging when imd_attn_params.k_pad_one; 11: the same with register staging; 9 / 7: the round-2 kernel with the same two staging
  * rules; 6, 8: scheduling variants of 7; 1..5: round-1 kernel shapes.  Values 20..39 (timing ablations that compute WRONG
  * results) are accepted only by a library built with -DIMD_ABLATIONS; a normal build rejects them);
  * knob 1: XCD-aware work mapping of the attention grid (0|1);

@@ -711,21 +711,27 @@ def test_attention(ops, D, B, N, L1, L2, dt):
     assert_close(out, ref, atol=1e-2, rtol=1e-2, what=f"attention D={D}")
 
 
-@pytest.mark.parametrize("variant", [10, 12, 11, 9, 7])
+@pytest.mark.parametrize("variant", [13, 12, 10, 11, 9, 7])
 @pytest.mark.parametrize("pad_one", [True, False])
 @pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (530, 700, 0), (512, 1000, 520), (768, 1408, 1216), (512, 1344, 64)])
 @DTS
 def test_attention_d40_kernel_variants(ops, N, L1, L2, pad_one, variant, dt):
-    """The software-pipelined head-dim-40 kernel (attention_d40.hip; N >= 512) in every shipped variant -- 10: head-dim rows
-    32..40 of P.V on v_mfma_f32_16x16x32 (default), 9: the round-2 kernel, 11 / 7: the same two with register staging --
-    with and without the caller's K pad-column guarantee (LDS-DMA vs register staging), ragged key counts, a second key
-    set on one of two batch rows, and a late spike that takes the exact (redo) path and raises the deferred maximum."""
+    """The software-pipelined head-dim-40 kernel (attention_d40.hip; N >= 512) in every shipped variant -- 13: the round-4 default
+    (bf16; fp16 runs 12), 12: compile-time ring slots, 10: head-dim rows 32..40 of P.V on v_mfma_f32_16x16x32 (round-3 default),
+    9: the round-2 kernel, 11 / 7: the same two with register staging -- with and without the caller's K pad-column guarantee
+    (LDS-DMA vs register staging), ragged key counts, a second key set on one of two batch rows, and a late spike that takes the
+    exact (redo) path and raises the deferred maximum."""
+    out, ref = _run_d40_variant(ops, N, L1, L2, pad_one, variant, 3.0, dt)
+    assert_close(out, ref, atol=1e-2 if dt == torch.float16 else 2e-2, rtol=2e-2, what=f"attention d40 variant {variant}")
+
+
+def _run_d40_variant(ops, N, L1, L2, pad_one, variant, spike, dt):
     D, H, B = 40, 8, 2
     Cc = H * D
     dpk, dpv = ops.attn_padded_dims(D)
     q = rnd(1, B, N, Cc).to(dt)
     k1 = rnd(2, B, L1, Cc).to(dt); v1 = rnd(3, B, L1, Cc).to(dt)
-    k1[:, L1 - 90] = q[:, 7] * 3.0                       # a key far above the rest late in the sequence
+    k1[:, L1 - 90] = q[:, 7] * spike                     # a key far above the rest late in the sequence
     scale = D ** -0.5 * math.log2(math.e)
 
     def kbuf(x):
@@ -738,21 +744,44 @@ def test_attention_d40_kernel_variants(ops, N, L1, L2, pad_one, variant, dt):
     kw = {}
     if L2:
         k2 = rnd(4, 1, L2, Cc).to(dt); v2 = rnd(5, 1, L2, Cc).to(dt)
-        k2[:, L2 - 40] = q[1, 300] * 3.0
+        k2[:, L2 - 40] = q[1, 300] * spike
         s2 = torch.tensor([0.9, 0.0])
         r2 = ref_attn(q, k2.expand(B, -1, -1), v2.expand(B, -1, -1), H)
         ref = ref.to(dt).float() + s2[:, None, None] * r2
         kw = dict(k2=kbuf(k2), v2t=dev(to_heads_t(v2, H, dpv, ops.pad64(L2), dt=dt)), scale2=dev(s2), L2=L2, L2P=ops.pad64(L2),
                   kv2_bdiv=B)
     lib = ops.L.load()
+    prev = lib.imd_get_tuning(0)
     ops.L.check(lib.imd_set_tuning(0, variant))
     try:
         ops.attention(dev(to_heads(q, H, dpk, scale, dt=dt)), kbuf(k1), dev(to_heads_t(v1, H, dpv, ops.pad64(L1), dt=dt)), out,
                       B=B, H=H, N=N, D=D, L1=L1, L1P=ops.pad64(L1), k_pad_one=pad_one, **kw)
         torch.cuda.synchronize()
     finally:
-        ops.L.check(lib.imd_set_tuning(0, 10))
-    assert_close(out, ref, atol=1e-2 if dt == torch.float16 else 2e-2, rtol=2e-2, what=f"attention d40 variant {variant}")
+        ops.L.check(lib.imd_set_tuning(0, prev))
+    assert torch.isfinite(out).all()
+    return out, ref
+
+
+@pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (512, 1000, 520), (768, 1408, 0)])
+def test_attention_d40_unchecked_steps_rerun_on_overflow(ops, N, L1, L2):
+    """Variant 13 (bf16 default) tests the deferred maximum only on the first and last steps of a phase.  A key whose score sits 170..400
+    (base-2 units) above everything the first block held makes P = 2^(s - m_ref) overflow fp32 for query 7 of every head: the
+    workgroups of query rows 0..255 find an infinite softmax denominator and run again as variant 12 -- their output must be variant
+    12's bit for bit (and finite: without the re-run those rows are NaN).  Workgroups whose scores stay below 2^127 keep the
+    unchecked result, which differs from 12's by rounding only (12 rescales where 13 lets P grow)."""
+    dt = torch.bfloat16
+    D, H = 40, 8
+    q = rnd(1, 2, N, H * D).to(dt).float().view(2, N, H, D)
+    k0 = rnd(2, 2, L1, H * D).to(dt).float().view(2, L1, H, D)
+    sc = D ** -0.5 * math.log2(math.e)
+    first = torch.einsum("bhd,bkhd->bhk", q[:, 7], k0[:, :32]).amax(-1) * sc          # query 7's maximum over the first 32-key block
+    late = (q[:, 7] * q[:, 7]).sum(-1) * 30.0 * sc                                     # ... and its score on the planted key
+    assert ((late - first) > 130).all()              # 2^(s - m_ref) is past fp32's range in every head
+    out13, _ = _run_d40_variant(ops, N, L1, L2, True, 13, 30.0, dt)
+    out12, _ = _run_d40_variant(ops, N, L1, L2, True, 12, 30.0, dt)
+    assert torch.equal(out13[:, :256], out12[:, :256])
+    assert_close(out13, out12, atol=2e-2, rtol=2e-2, what="variant 13 vs 12 under large scores")
 
 
 @pytest.mark.parametrize("pad_one", [True, False])
