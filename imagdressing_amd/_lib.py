@@ -114,6 +114,7 @@ SYMBOLS = {
     "imd_conv_patch2_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_conv_patch3_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_conv_patch4_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
+    "imd_conv_img_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_conv_patch_stats_parts": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_conv_gemm_stats_parts": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int]),
     "imd_gemm_dma_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),

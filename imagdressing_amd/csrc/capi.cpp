@@ -134,6 +134,7 @@ int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (sized(p) &
 int imd_conv_patch2_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch2_supported(*p)) ? 1 : 0; }
 int imd_conv_patch3_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch3_supported(*p)) ? 1 : 0; }
 int imd_conv_patch4_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch4_supported(*p)) ? 1 : 0; }
+int imd_conv_img_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_img_supported(*p)) ? 1 : 0; }
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return sized(p) ? imd_conv_patch_stats_parts_of(*p) : 0; }
 int imd_conv_gemm_stats_parts(const imd_conv_gemm_params* p, int cfg) { return sized(p) ? imd_conv_gemm_stats_parts_of(*p, cfg) : 0; }
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_gemm_dma_supported(*p)) ? 1 : 0; }

@@ -456,6 +456,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 9: case 21: *bm = 256; *bn = 128; return 0;
         case 22: *bm = 128; *bn = 160; return 0;
         case 23: *bm = 256; *bn = 160; return 0;
+        case 24: *bm = 512; *bn = 64; return 0;
         case 10: case 16: *bm = 256; *bn = 256; return 0;
         case 17: case 18: case 19: case 20: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
@@ -484,7 +485,7 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || cfg == 22 || cfg == 23 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
@@ -596,6 +597,13 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             if (rc || p.split_k <= 1) return rc;
             p.splitk_counters = nullptr;
             return launch_splitk_finish(p, s, "conv_patch3 split-K finish");
+        }
+        case 24: {  // whole small maps (8 pixels wide) x 64 channels x one K slice per workgroup (conv_img.hip): every weight byte fetched once
+            p.splitk_counters = nullptr;
+            if (p.split_k <= 1) return imd_set_error("conv_gemm: tile config 24 writes K-slice slabs only (split_k >= 2)");
+            int rc = imd_launch_conv_img(p, s);
+            if (rc) return rc;
+            return launch_splitk_finish(p, s, "conv_img split-K finish");
         }
         case 12: return imd_launch_row_linear(p, 0, 0.f, s);      // row-resident kernel (row_linear.hip): K = 320, N <= 320
         case 13: return imd_launch_row_linear_k640(p, 0, 0.f, s); // row-resident split-K kernel (row_linear_k640.hip): K = 640, N % 160 == 0

@@ -157,7 +157,7 @@ def _gemm_table() -> dict:
     if _GEMM_TABLE is None:
         import json
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning.json")
+        path = os.environ.get("IMD_GEMM_TUNING") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tuning.json")      # (override: A/B of two tables)
         try:
             with open(path) as f:
                 _GEMM_TABLE = json.load(f).get("shapes", {})
@@ -268,6 +268,10 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg == 23 and not lib.imd_conv_patch4_supported(C.byref(p)):
                 cfg, split_k = -1, 0
+            if cfg == 24:                       # whole-map kernel of the 8-wide levels: K-sliced only
+                p.split_k = split_k
+                if not lib.imd_conv_img_supported(C.byref(p)):
+                    cfg, split_k = -1, 0
     # shapes outside the measured table: 3x3 stride-1 convs on wide maps go to the halo-patch kernel (always ahead of the
     # gather kernel there: profiles/r1k_patch_conv_ab.jsonl)
     if PATCH_CONV and cfg == -1 and taps == 9 and stride == 1 and Wout >= PATCH_MIN_W and N >= 64 \

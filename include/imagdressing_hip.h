@@ -207,6 +207,8 @@ int imd_device_check(int device);
  * 21: the halo-patch kernel with 16 x 16 pixel tiles (256 pixels x 128 channels per workgroup, wave tiles 128 x 64: half the weight bytes per MAC);
  * 22: the halo-patch kernel with 8 x 16 pixels x 160 channels per workgroup (wave tiles 32 x 160: N = 320 k runs without idle waves or padded MFMAs);
  * 23: 22 with eight waves = 16 x 16 pixels x 160 channels per workgroup (one staged weight tile serves 256 pixels: 154 instead of 290 bytes of LDS-DMA per MFMA).
+ * 24: 3x3 stride-1 convolutions of maps 8 pixels wide (the UNet's lowest level): a workgroup owns all pixels of up to 8 images x 64 channels x one
+ *     K slice, so every weight byte is fetched once; K-sliced only (split_k >= 2).
  * Results are identical up to fp32 summation order. */
 int imd_conv_gemm(const imd_conv_gemm_params* p, int cfg, void* stream);
 int imd_conv_gemm_auto_cfg(int M, int N);
@@ -262,6 +264,9 @@ int imd_conv_patch2_supported(const imd_conv_gemm_params* p);
 int imd_conv_patch3_supported(const imd_conv_gemm_params* p);
 /* 1 iff tile config 23 (the same kernel with eight waves: 16 x 16 pixels x 160 channels per workgroup) takes this geometry */
 int imd_conv_patch4_supported(const imd_conv_gemm_params* p);
+/* 1 iff tile config 24 (conv_img.hip: whole maps 8 pixels wide x 64 channels x one K slice per workgroup, split_k >= 2) takes this problem;
+ * split_k must be filled in as imd_conv_gemm will see it */
+int imd_conv_img_supported(const imd_conv_gemm_params* p);
 /* number of statistic partials per image the halo-patch kernel writes for this geometry (gn_stats_out), 0 if it cannot */
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p);
 /* the same for ANY launch: partials per image that imd_conv_gemm(p, cfg) writes through gn_stats_out -- the halo-patch epilogue (cfg 5, no K

@@ -405,7 +405,7 @@ def test_tuning_table_only_names_known_tile_configs():
             Ho, Wo = map(int, geom.split("x"))
             assert taps == 9 and M % (Ho * Wo) == 0, key
         for c in (ent["cfg"], ent["cfg_nosplit"]):
-            assert c in range(0, 24), (key, ent)
+            assert c in range(0, 25), (key, ent)
             if c in (17, 19): assert K % 64 == 0 and taps == 1, key
             if c in (18, 20): assert taps == 9 and (K // 9) % 32 == 0, key
             if c == 12: assert K == 320 and N <= 320 and N % 64 == 0 and taps == 1, key
@@ -416,6 +416,8 @@ def test_tuning_table_only_names_known_tile_configs():
             if c in (5, 21, 22, 23):
                 assert taps == 9 and stride == 1, key
                 if geom: assert Wo >= 16 and Ho >= 8, key          # the halo-patch kernel's 8 x 16 pixel tiles
+            if c == 24:
+                assert taps == 9 and stride == 1 and geom and Wo == 8 and Ho <= 12 and ent["split"] >= 2 and N % 64 == 0 and (K // 9) % 32 == 0, key
         assert ent["split"] >= 1 and (ent["split"] == 1 or ent["cfg"] not in (12, 13, 14, 15, 16)), (key, ent)
 
 

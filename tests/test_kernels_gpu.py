@@ -569,7 +569,40 @@ def test_conv3x3_epilogue_groupnorm_statistics(ops, B, H, W, Cin, Cout, G, cfg, 
     assert getattr(out2, "_imd_gn_stats", None) is not None
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,split", [
+    (8, 8, 1280, 1280, 12),       # the 8x8-level conv of the bench batch: 8 images = 8 waves, 40 chunks over 12 slices (4 / 3 per slice)
+    (8, 8, 2560, 128, 12),        # the up block's wide input
+    (2, 8, 320, 64, 3),           # batch 1 (2 CFG rows): two waves
+    (3, 8, 64, 192, 2),           # a ragged image group (3 of 4 waves own an image), 2 chunks per slice
+    (11, 8, 96, 64, 4),           # two image groups, the second ragged; 3 chunks over 4 slices (one slice is empty)
+    (4, 10, 160, 128, 5),         # the 10 x 8 level of the 512 x 640 geometry: three pixel blocks per image, the last half empty
+    (5, 12, 32, 64, 2),           # 12 rows: the tallest map the kernel takes
+    (1, 5, 32, 64, 2),            # one chunk (the second slice is empty), a short map
+])
+@DTS
+def test_conv3x3_whole_small_maps(ops, B, H, Cin, Cout, split, dt):
+    """tile config 24 (conv_img.hip: all pixels of up to 8 images x 64 channels x one K slice per workgroup, both operands by LDS-DMA
+    into plane-layout ring slots) == F.conv2d on maps 8 pixels wide, finished by the shared split-K launch with the full epilogue."""
+    W = 8
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, H, W, Cout).to(dt)
+    ref = (F.conv2d(x.float(), w.float(), b, padding=1) + temb[:, :, None, None]).permute(0, 2, 3, 1) + res.float()
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), taps=9, rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), cfg=24, split_k=split)
+    assert_close(out, ref, what=f"conv3x3 cfg=24 B={B} H={H}")
+    # a pixel-strided input (channels 16 .. 16 + Cin of a wider NHWC buffer): same result
+    wide = torch.full((B * H * W, Cin + 24), 7.0, dtype=dt, device="cuda")
+    wide[:, :Cin] = xd.view(-1, Cin)
+    out2 = ops.conv_gemm(wide, dev(pack_conv(w)), M=B * H * W, N=Cout, Cin=Cin, taps=9, Hin=H, Win=W, Hout=H, Wout=W, bias=dev(b),
+                         rowvec=dev(temb), rowvec_stride=Cout, res=dev(res).view(-1, Cout), cfg=24, split_k=split, x_pix_stride=Cin + 24)
+    assert torch.equal(out.view(-1, Cout), out2)
+    with pytest.raises(ops.L.ImdError):           # un-split: refused, the kernel has no epilogue of its own
+        ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), taps=9, cfg=24, split_k=1)
+
+
 @pytest.mark.parametrize("cfg,B,H,W,Cin,Cout,G,split,stride", [
+    (24, 8, 8, 8, 640, 1280, 32, 6, 1),        # the whole-map kernel of the 8-wide levels (always K-sliced)
     (2, 8, 8, 8, 1280, 1280, 32, 6, 1),        # the 8x8-level weight-streaming conv of the bench batch (64^2 register-staged tiles)
     (18, 2, 8, 8, 320, 1280, 32, 3, 1),        # gathering LDS-DMA tiles
     (5, 2, 16, 16, 640, 1280, 32, 4, 1),       # halo-patch kernel with K slices

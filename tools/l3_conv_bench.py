@@ -6,12 +6,12 @@ import torch
 from imagdressing_amd import ops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--cfgs", default="0,1,2,3,5,18")
+ap.add_argument("--cfgs", default="0,1,2,3,5,18,24")
 ap.add_argument("--splits", default="1,2,3,4,6,8,9,12,18")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--shapes", default="L3a,L3b,L2a")
 a = ap.parse_args()
-SH = {"L3a": (16, 8, 8, 1280, 1280), "L3b": (16, 8, 8, 2560, 1280), "L2a": (16, 16, 16, 1280, 1280), "L2b": (16, 16, 16, 2560, 1280),
+SH = {"L3c": (8, 8, 8, 2560, 1280), "L3one": (2, 8, 8, 1280, 1280), "L3a": (16, 8, 8, 1280, 1280), "L3b": (16, 8, 8, 2560, 1280), "L2a": (16, 16, 16, 1280, 1280), "L2b": (16, 16, 16, 2560, 1280),
       "L3s": (8, 8, 8, 1280, 1280)}
 dt = torch.bfloat16
 def linear_case(M, N, K):
