@@ -112,6 +112,19 @@ def test_pure_queries_work_without_gpu(lib):
     assert lib.imd_groupnorm_workspace_floats(8, 4096, 320, 32) == 8 * 64 * 32 * 2 + 2 * 8 * 320       # 64-pixel chunk partials (512-block target) + coefficients
     assert lib.imd_groupnorm_workspace_floats(8, 64, 1280, 32) == 8 * 16 * 32 * 2 + 2 * 8 * 1280         # 4-pixel chunks at 8x8
     assert lib.imd_conv_gemm_auto_cfg(32768, 320) in (0, 1, 2, 4)
+    # tile config 24 (whole 8-wide maps, K-sliced only): a pure predicate over the parameter block
+    from imagdressing_amd import _lib
+    q = _lib.ConvGemmParams()
+    q.M, q.N, q.K, q.Cin, q.taps, q.stride = 8 * 64, 1280, 9 * 1280, 1280, 9, 1
+    q.Hin = q.Win = q.Hout = q.Wout = 8
+    q.x_pix_stride, q.split_k = 1280, 6
+    assert lib.imd_conv_img_supported(ctypes.byref(q)) == 1
+    for field, bad in (("split_k", 1), ("Wout", 16), ("Cin", 1296), ("N", 1248), ("stride", 2), ("Hout", 13), ("out_f32", 1)):
+        keep = getattr(q, field)
+        setattr(q, field, bad)
+        assert lib.imd_conv_img_supported(ctypes.byref(q)) == 0, field
+        setattr(q, field, keep)
+    assert lib.imd_conv_img_supported(ctypes.byref(q)) == 1
 
 
 def test_no_cpu_path():
