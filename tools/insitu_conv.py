@@ -9,6 +9,8 @@ from imagdressing_amd import ops
 ap = argparse.ArgumentParser()
 ap.add_argument("--force", nargs="*", default=[]); ap.add_argument("--top", type=int, default=30); ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--taps", type=int, default=0, help="only keys with this many taps (9 | 1)")
+ap.add_argument("--batch", type=int, default=4, help="images per batch (1: the latency shapes)")
+ap.add_argument("--grep", default="", help="only keys containing this text")
 a = ap.parse_args()
 tab = ops._gemm_table()
 for f in a.force:
@@ -19,10 +21,10 @@ for f in a.force:
     tab[key] = ent
 dev = torch.device("cuda", 0)
 pipe = bench.build_pipeline(dev, torch.bfloat16, 0)
-inp = bench.synthetic_inputs(512, 512, 4, dev, torch.bfloat16, 0, 1)
+inp = bench.synthetic_inputs(512, 512, a.batch, dev, torch.bfloat16, 0, 1)
 def run():
     return pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=512, height=512, num_inference_steps=a.steps,
-                guidance_scale=7.5, num_images_per_prompt=4, output_type="latent", **inp).images
+                guidance_scale=7.5, num_images_per_prompt=a.batch, output_type="latent", **inp).images
 run(); torch.cuda.synchronize()
 ops.GEMM_EVENT_HOOK = {}
 run(); torch.cuda.synchronize()
@@ -35,4 +37,5 @@ tot = sum(r["total_ms"] for r in rows)
 print(json.dumps(dict(total_ms_in_conv_gemm_launches=round(tot, 2), steps=a.steps)))
 for r in sorted(rows, key=lambda r: -r["total_ms"])[:a.top]:
     if a.taps and f",{a.taps}," not in r["key"]: continue
+    if a.grep and a.grep not in r["key"]: continue
     print(json.dumps(r))
