@@ -10,6 +10,7 @@
 #   ab-env TAG VAR V1 V2 [args]    same-box A/B of one environment variable, interleaved twice (quick bench)
 #   ab-lib TAG L1 L2 ...           same-box A/B of library builds imagdressing_amd/libimagdressing_hip_<L>.so ("cur" = shipped)
 #   pmc    OUT PATTERN cmd...      PMC counters of the kernels matching PATTERN in cmd (separate passes, --kernel-trace only)
+#   prof   TAG cmd...              rocprofv3 --kernel-trace --stats of any command -> gpurun_out/TAG_kernel_trace_summary.md (HEAD lines printed, default 30)
 #   run    TAG cmd...              any command, stdout+stderr -> gpurun_out/TAG.txt (tail printed)
 R="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$R"; mkdir -p gpurun_out
@@ -47,6 +48,14 @@ case "$task" in
       if [ $lib = cur ]; then unset IMD_LIB_PATH; else export IMD_LIB_PATH=$R/imagdressing_amd/libimagdressing_hip_$lib.so; fi
       timeout 400 python bench.py --steps 3 --warmup 1 $QUICK 2>/dev/null | line "lib=$lib"
     done; done | tee gpurun_out/${tag}_ab.txt ;;
+  prof)
+    tag="$1"; shift
+    mkdir -p gpurun_out/$tag
+    (cd /tmp && export TMPDIR=/tmp && cd $R && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$tag -o trace -- "$@" > $R/gpurun_out/${tag}_cmd.out 2> $R/gpurun_out/${tag}_rocprof.err)
+    DB=$(find gpurun_out/$tag -name "*.db" | head -1)
+    python tools/rocprof_summary.py $DB gpurun_out/${tag}_kernel_trace_summary.md
+    head -${HEAD:-30} gpurun_out/${tag}_kernel_trace_summary.md
+    find gpurun_out/$tag -name "*.db" -size +20000k -delete ;;
   pmc)
     OUT="$1"; PAT="$2"; shift 2
     mkdir -p $R/$OUT; i=0
