@@ -71,7 +71,19 @@ static void run(const char* what, int m_tiles, int n_tiles, int gy, int flags) {
            "\"mean_xccs_per_row_tile\": %.3f, \"mean_xccs_per_channel_tile\": %.3f, \"first_16_xcc\": [",
            what, gx, gy, flags, off, (double)lin_ok / (gx * (double)gy), (double)x_ok / (gx * (double)gy), rs / m_tiles, cs / n_tiles);
     for (int i = 0; i < 16 && i < (int)gx; ++i) printf("%u%s", h[(size_t)i * 4], i == 15 || i + 1 == (int)gx ? "" : ", ");
-    printf("]}\n");
+    printf("]");
+    if (getenv("XCC_PROBE_CU")) {       // which CU hosts the j-th block of XCC 0?  HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+        printf(", \"cu_key_of_xcc0_blocks\": [");
+        int n = 0;
+        for (unsigned x = 0; x < gx && n < 128; ++x)
+            if (h[(size_t)x * 4] == (unsigned)off) {
+                const uint32_t w = h[(size_t)x * 4 + 1];
+                printf("%s%u", n ? ", " : "", ((w >> 13) & 7u) * 32 + ((w >> 12) & 1u) * 16 + ((w >> 8) & 15u));
+                ++n;
+            }
+        printf("]");
+    }
+    printf("}\n");
     hipFree(d);
 }
 
