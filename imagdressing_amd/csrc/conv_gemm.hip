@@ -458,7 +458,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 23: *bm = 256; *bn = 160; return 0;
         case 24: *bm = 512; *bn = 64; return 0;
         case 10: case 16: *bm = 256; *bn = 256; return 0;
-        case 17: case 18: case 19: case 20: *bm = 128; *bn = 128; return 0;
+        case 17: case 18: case 19: case 20: case 25: case 26: case 27: case 28: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
         default: return 1;
     }
@@ -485,7 +485,7 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || (cfg >= 17 && cfg <= 20)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
@@ -597,6 +597,13 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             if (rc || p.split_k <= 1) return rc;
             p.splitk_counters = nullptr;
             return launch_splitk_finish(p, s, "conv_patch3 split-K finish");
+        }
+        case 25: case 26: case 27: case 28: {   // the 128 x 128 LDS-DMA tiles with 128-BYTE rows (BK = 64): 25 / 27 plain linears with two / three stages, 26 / 28 3x3 convs
+            if ((cfg == 26 || cfg == 28) != (p.taps == 9)) return imd_set_error("conv_gemm: tile config %d does not take taps = %d", cfg, p.taps);
+            p.splitk_counters = nullptr;
+            int rc = imd_launch_gemm_dma128(p, cfg >= 27 ? 13 : 12, s);
+            if (rc || p.split_k <= 1) return rc;
+            return launch_splitk_finish(p, s, "gemm_dma128 split-K finish");
         }
         case 24: {  // whole small maps (8 pixels wide) x 64 channels x one K slice per workgroup (conv_img.hip): every weight byte fetched once
             p.splitk_counters = nullptr;

@@ -169,10 +169,19 @@ static_assert(3 * G1_STAGE >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");
 // taps of the same channels), an A row's 64 bytes are the 32 channels of ONE input pixel, and the per-lane DMA offset is
 // recomputed per tile from the row's top-left tap position; halo pixels are out-of-range offsets.  Serves the maps the halo-patch
 // kernel cannot tile (8 x 8) and the stride-2 convs.
-template <bool F16, bool GATHER, int G1_NST>
-__global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(const ConvGemmParams p) {
+// BK = 64 (tile configs 25 / 26 / 27; round 4): 128-BYTE rows.  The L2 hands a CU one 128-byte line per request whatever part of it was asked for
+// (tools/probes/staging_probe.hip: 62 GB/s per CU in 64-byte segments, 113 GB/s in 128-byte segments) -- the 64-byte rows of BK = 32 use half of
+// every line they pull.  Stage = 32 KB (two stages = 64 KB = two workgroups per CU, three = 96 KB = one), eight pieces per wave and tile, piece
+// c of row r at c ^ ((r >> 1) & 7).
+template <bool F16, bool GATHER, int G1_NST, int BK = 32>
+__global__ __launch_bounds__(256, (G1_NST * (G1_BM + G1_BN) * BK * 2 <= 49152) ? 3 : (G1_NST * (G1_BM + G1_BN) * BK * 2 <= 65536) ? 2 : 1)
+void gemm_dma128_kernel(const ConvGemmParams p) {
     using E = El<F16>;
-    constexpr int G1_KEEP = (G1_NST - 2) * 4;                  // pieces of the younger tiles that may stay in flight at the per-tile wait
+    constexpr int ROWB = BK * 2, LPR = ROWB / 16;              // bytes / 16-byte pieces per row
+    constexpr int STAGE = (G1_BM + G1_BN) * ROWB;
+    constexpr int PPW = G1_BM * ROWB / 1024 / 4;               // pieces per wave and operand tile: 2 | 4
+    constexpr int NP = 2 * PPW;
+    constexpr int G1_KEEP = (G1_NST - 2) * NP;                 // pieces of the younger tiles that may stay in flight at the per-tile wait
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(c
     xcd_tile_order(p.flags, (p.M + G1_BM - 1) / G1_BM, n_tiles, tile_m, tile_n);
     const int m0 = tile_m * G1_BM, n0 = tile_n * G1_BN;
     // K range of this slice (split-K: blockIdx.y; fp32 slabs + the fixed-order finish launch of conv_gemm.hip)
-    const int nk_total = p.K / G1_BK;              // (GATHER: 9 taps x Cin / 32 channel chunks)
+    const int nk_total = p.K / BK;                 // (GATHER: 9 taps x Cin / BK channel chunks)
     const int per = (nk_total + p.split_k - 1) / p.split_k;
     const int kt0 = blockIdx.y * per;
     const int nk = max(0, min(nk_total, kt0 + per) - kt0);
@@ -193,14 +202,16 @@ __global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(c
     // a stage = 16 pieces of 1 KB (16 rows x 64 B each): pieces 0..7 activation rows, 8..15 weight rows; wave w issues pieces
     // w, w + 4 (activations) and 8 + w, 12 + w (weights)
     const v4i_t ds_x = raw_rsrc(p.x, p.x_bytes), ds_w = raw_rsrc(p.w, p.w_bytes);
-    uint32_t soff[4];
-    int g_base[2] = {-1, -1}, g_y0[2] = {0, 0}, g_x0[2] = {0, 0}, g_pc[2] = {0, 0};        // GATHER: per A piece (row) of this lane
+    uint32_t soff[NP];
+    int g_base[PPW], g_y0[PPW], g_x0[PPW], g_pc[PPW];        // GATHER: per A piece (row) of this lane
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) { g_base[j] = -1; g_y0[j] = 0; g_x0[j] = 0; g_pc[j] = 0; }
     const int Hl = p.ups ? p.Hin * 2 : p.Hin, Wl = p.ups ? p.Win * 2 : p.Win;              // logical (post-upsample) input map
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int id = (j & 1) * 4 + wave;                    // piece inside its operand tile
-        const int q = id * 64 + lane, row = q >> 2, pc = (q & 3) ^ ((row >> 2) & 3);
-        if (j >= 2) soff[j] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + pc * 8) * 2) : OOB;
+    for (int j = 0; j < NP; ++j) {
+        const int id = (j % PPW) * 4 + wave;                  // piece inside its operand tile
+        const int q = id * 64 + lane, row = q / LPR, pc = (q % LPR) ^ (BK == 32 ? (row >> 2) & 3 : (row >> 1) & 7);
+        if (j >= PPW) soff[j] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + pc * 8) * 2) : OOB;
         else if (!GATHER) soff[j] = (m0 + row < p.M) ? (uint32_t)(((size_t)(m0 + row) * p.x_pix_stride + pc * 8) * 2) : OOB;
         else {
             soff[j] = OOB;
@@ -213,23 +224,23 @@ __global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(c
         }
     }
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-    const int nchunk = GATHER ? p.Cin / G1_BK : 1;
+    const int nchunk = GATHER ? p.Cin / BK : 1;
     auto stage = [&](int kt, int slot) {                      // (tiles past the end: zero-fill pieces keep the counted waits uniform)
-        const uint32_t base = lds0 + (uint32_t)(slot * G1_STAGE);
+        const uint32_t base = lds0 + (uint32_t)(slot * STAGE);
         const int kg = kt0 + kt;
         int ky = 0, kx = 0, ci = 0;
-        uint32_t wk = (uint32_t)(kg * G1_BK * 2);             // byte offset of the tile inside a weight row
+        uint32_t wk = (uint32_t)(kg * BK * 2);                // byte offset of the tile inside a weight row
         if (GATHER) {                                         // tap-inner tile order: tile kg -> (channel chunk kg / 9, tap kg % 9)
             const int c = kg / 9, tap = kg - 9 * c;
-            ky = tap / 3; kx = tap - 3 * ky; ci = c * G1_BK;
+            ky = tap / 3; kx = tap - 3 * ky; ci = c * BK;
             wk = (uint32_t)((tap * p.Cin + ci) * 2);
             (void)nchunk;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int id = (j & 1) * 4 + wave + (j >= 2 ? 8 : 0);
+        for (int j = 0; j < NP; ++j) {
+            const int id = (j % PPW) * 4 + wave + (j >= PPW ? 4 * PPW : 0);
             uint32_t off;
-            if (j >= 2) off = (soff[j] == OOB || kt >= nk) ? OOB : soff[j] + wk;
+            if (j >= PPW) off = (soff[j] == OOB || kt >= nk) ? OOB : soff[j] + wk;
             else if (!GATHER) off = (soff[j] == OOB || kt >= nk) ? OOB : soff[j] + wk;
             else {
                 const int iy = g_y0[j] + ky, ix = g_x0[j] + kx;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(c
                 const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
                 off = ok ? (uint32_t)((g_base[j] + sy * p.Win + sx) * p.x_pix_stride + ci + g_pc[j]) * 2u : OOB;
             }
-            dma16(j >= 2 ? ds_w : ds_x, base + (uint32_t)id * 1024u, off);
+            dma16(j >= PPW ? ds_w : ds_x, base + (uint32_t)id * 1024u, off);
         }
     };
 
@@ -249,9 +260,10 @@ __global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // fragment addresses (16-deep slice kk = 0; kk = 1 is the same address ^ 32): row offsets are multiples of 32, so the swizzle
-    // term (row >> 2) & 3 of row (base + col) is (col >> 2) & 3
-    const int fo = col * 64 + ((hi ^ ((col >> 2) & 3)) << 4);
+    // fragment addresses (16-deep slice kk: piece 2 kk + hi): row offsets are multiples of 32, so the swizzle term of row (base + col) is col's
+    int fo[BK / 16];
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) fo[kk] = col * ROWB + (((2 * kk + hi) ^ (BK == 32 ? (col >> 2) & 3 : (col >> 1) & 7)) << 4);
     const bool wave_live = n0 + wn0 < p.N && m0 + wm0 < p.M;
 
 #pragma unroll
@@ -263,15 +275,15 @@ __global__ __launch_bounds__(256, G1_NST <= 3 ? 3 : 2) void gemm_dma128_kernel(c
     for (int kt = 0; kt < nk; ++kt) {
         stage(kt + G1_NST - 1, slot == 0 ? G1_NST - 1 : slot - 1);   // slot (kt - 1) % NST: last read at tile kt - 1, everybody is past that barrier
         if (wave_live) {
-            const char* Xs = smem + slot * G1_STAGE + wm0 * 64;
-            const char* Ws = smem + slot * G1_STAGE + G1_BM * 64 + wn0 * 64;
+            const char* Xs = smem + slot * STAGE + wm0 * ROWB;
+            const char* Ws = smem + slot * STAGE + G1_BM * ROWB + wn0 * ROWB;
 #pragma unroll
-            for (int kk = 0; kk < G1_BK / 16; ++kk) {
+            for (int kk = 0; kk < BK / 16; ++kk) {
                 uint4 wf[2], xf[2];
 #pragma unroll
-                for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + ((a * 32 * 64 + fo) ^ (kk * 32)));
+                for (int a = 0; a < 2; ++a) wf[a] = *reinterpret_cast<const uint4*>(Ws + a * 32 * ROWB + fo[kk]);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xs + ((b * 32 * 64 + fo) ^ (kk * 32)));
+                for (int b = 0; b < 2; ++b) xf[b] = *reinterpret_cast<const uint4*>(Xs + b * 32 * ROWB + fo[kk]);
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -341,13 +353,14 @@ bool imd_conv_dma_supported(const ConvGemmParams& p) {       // tile config 18: 
            (p.x_pix_stride % 8) == 0 && (!p.ups || p.stride == 1);
 }
 
-template <bool GATHER, int NST>
+template <bool GATHER, int NST, int BK = 32>
 static int launch_dma128(const ConvGemmParams& p, hipStream_t s, const char* what) {
     static bool attr_set[2] = {false, false};
-    constexpr int LDS = NST * G1_STAGE;        // 49152 (three stages) | 65536 (four)
+    constexpr int LDS = NST * (G1_BM + G1_BN) * BK * 2;        // BK = 32: 49152 (three stages) | 65536 (four); BK = 64: 65536 (two) | 98304 (three)
+    static_assert(LDS >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
-    const kern_t kern = h ? gemm_dma128_kernel<true, GATHER, NST> : gemm_dma128_kernel<false, GATHER, NST>;
+    const kern_t kern = h ? gemm_dma128_kernel<true, GATHER, NST, BK> : gemm_dma128_kernel<false, GATHER, NST, BK>;
     if (!attr_set[h]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
@@ -362,6 +375,16 @@ static int launch_dma128(const ConvGemmParams& p, hipStream_t s, const char* wha
 int imd_launch_gemm_dma128(const ConvGemmParams& p_in, int stages, hipStream_t s) {
     ConvGemmParams p = p_in;
     p.splitk_counters = nullptr;               // (the in-kernel reduction lives in the register-staged kernels only)
+    if (stages == 12 || stages == 13) {       // 128-byte rows (BK = 64): two | three ring stages
+        if (p.taps == 9) {
+            if (!imd_conv_dma_supported(p) || (p.Cin % 64)) return imd_set_error("conv_dma (128-byte rows): needs a 3x3 convolution with Cin %% 64 == 0 (got Cin=%d stride=%d)", p.Cin, p.stride);
+            return stages == 12 ? launch_dma128<true, 2, 64>(p, s, "conv_dma128 (BK 64)") : launch_dma128<true, 3, 64>(p, s, "conv_dma128 (BK 64, 3 stages)");
+        }
+        ConvGemmParams p1 = p;
+        p1.split_k = 1;
+        if (!imd_gemm_dma_supported(p1)) return imd_set_error("gemm_dma128: needs a plain linear layer with K %% 64 == 0 (got K=%d taps=%d)", p.K, p.taps);
+        return stages == 12 ? launch_dma128<false, 2, 64>(p, s, "gemm_dma128 (BK 64)") : launch_dma128<false, 3, 64>(p, s, "gemm_dma128 (BK 64, 3 stages)");
+    }
     if (stages != 3 && stages != 4) return imd_set_error("gemm_dma128: %d ring stages (3 | 4)", stages);
     if (p.taps == 9) {
         if (!imd_conv_dma_supported(p)) return imd_set_error("conv_dma: needs a 3x3 convolution with Cin %% 32 == 0 (got Cin=%d stride=%d)", p.Cin, p.stride);

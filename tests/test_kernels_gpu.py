@@ -84,7 +84,7 @@ def test_linear_epilogues(ops, dt):
 
 @DTS
 @pytest.mark.parametrize("M,N,K,split,cfg", [(512, 1280, 11520, 6, 0), (200, 320, 2304, 3, 2), (2048, 132, 4096, 4, 1), (64, 64, 8192, 8, -1), (300, 640, 2560, 5, 6), (130, 64, 4096, 7, 7), (600, 384, 2048, 3, 9), (520, 520, 1024, 2, 10),
-                                                  (512, 1280, 5120, 3, 17), (300, 132, 2048, 4, 17)])
+                                                  (512, 1280, 5120, 3, 17), (300, 132, 2048, 4, 17), (512, 1280, 5120, 3, 25), (300, 132, 2048, 4, 27)])
 def test_linear_split_k(ops, M, N, K, split, cfg, dt):
     """K slices into fp32 slabs + fixed-order finish kernel == unsplit result (bias + residual + SiLU epilogue)."""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
@@ -286,11 +286,11 @@ def test_row_qkv(ops, ln, dt):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 320, 320), (1000, 2560, 640), (77, 64, 768), (520, 1284, 1280), (2048 + 19, 520, 128)])
-@pytest.mark.parametrize("cfg", [16, 17, 19])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27])
 @DTS
 def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
-    """tile configs 16 (256 x 256 x 64, two stages), 17 and 19 (128 x 128 x 32, three- / four-stage ring, round 3): both operands by LDS-DMA
-    (gemm_dma.hip) == x W^T + b, with the shared epilogues"""
+    """tile configs 16 (256 x 256 x 64, two stages), 17 and 19 (128 x 128 x 32, three- / four-stage ring, round 3), 25 and 27 (128 x 128 x 64:
+    128-byte rows, two / three stages, round 4): both operands by LDS-DMA (gemm_dma.hip) == x W^T + b, with the shared epilogues"""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
     base = x.float() @ w.float().t() + b
     assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=cfg), base, what="gemm_dma")
@@ -305,7 +305,7 @@ def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
         ops.linear(dev(rnd(1, 64, 72).to(dt)), dev(rnd(2, 64, 72).to(dt)), cfg=cfg)           # K % 64 != 0: refused
 
 
-@pytest.mark.parametrize("cfg", [16, 17, 19])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27])
 @DTS
 def test_gemm_dma_head_split(ops, dt, cfg):
     """head-split q / k / v epilogue through tile config 16 (the 32x32-level projection: 8 heads x 80)"""
@@ -408,11 +408,12 @@ def _halo_patch_case(ops, B, H, W, Cin, Cout, split, dt):
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride,split", [(8, 8, 8, 1280, 1280, 1, 6), (8, 16, 16, 640, 128, 2, 3), (2, 8, 8, 2560, 132, 1, 8),
                                                        (1, 17, 9, 64, 64, 2, 1)])
-@pytest.mark.parametrize("cfg", [18, 20])
+@pytest.mark.parametrize("cfg", [18, 20, 26, 28])
 @DTS
 def test_conv3x3_dma_gather_split_k(ops, B, H, W, Cin, Cout, stride, split, dt, cfg):
-    """tile configs 18 / 20 (3x3 conv gathered tile by tile into the three- / four-stage LDS-DMA ring of gemm_dma.hip) on the maps the halo-patch
-    kernel cannot tile -- 8 x 8, stride 2, odd sizes -- with K slices and the full epilogue"""
+    """tile configs 18 / 20 (3x3 conv gathered tile by tile into the three- / four-stage LDS-DMA ring of gemm_dma.hip; 26 / 28: the 128-byte-row
+    form, one tap x 64 channels per tile) on the maps the halo-patch kernel cannot tile -- 8 x 8, stride 2, odd sizes -- with K slices and the
+    full epilogue"""
     x = rnd(1, B, Cin, H, W).to(dt)
     w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
     b = rnd(3, Cout)

@@ -69,7 +69,14 @@ def only_linear(args, shapes, dt):
         shipped = (ent["cfg"], ent["split"]) if t["any_splittable"] else (ent["cfg_nosplit"], 1)
         cands = {}
         for rep in range(2):
-            for cand in [shipped] + [(c, 1) for c in (0, 4, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19) if (c, 1) != shipped]:
+            if args.cands:          # a focused re-time: the shipped choice against the named tile configs (un-split, and at the shipped K split)
+                cc = [int(c) for c in args.cands.split(",")]
+                others = [(c, 1) for c in cc] + ([(c, shipped[1]) for c in cc] if shipped[1] > 1 else [])
+                if t["K"] % 64 or t["K"] < args.min_k:
+                    continue
+            else:
+                others = [(c, 1) for c in (0, 4, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19)]
+            for cand in [shipped] + [c for c in others if c != shipped]:
                 try:
                     us = time_candidate(t, cand[0], cand[1], dt, args.iters)
                 except Exception:          # noqa
@@ -112,6 +119,8 @@ def main():
     ap.add_argument("--out", default="gpurun_out/gemm_tuning.json")
     ap.add_argument("--only-conv3x3", action="store_true",
                     help="re-time only the 3x3 stride-1 convolutions (candidates 0, 4, 5) and merge into the shipped table")
+    ap.add_argument("--cands", default="", help="with --only-linear: comma list of tile configs to time against the shipped choice (e.g. 25,27)")
+    ap.add_argument("--min-k", type=int, default=0, help="with --cands: only shapes with K >= this")
     ap.add_argument("--only-linear", action="store_true",
                     help="re-time only the plain linear layers (taps = 1) with the shipped choice against the unsplit candidates 0, 4, 9, 10, 11 and "
                          "the round-2 kernels 12..16; an entry changes only when the winner is > 3 %% faster than the shipped choice")

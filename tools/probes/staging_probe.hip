@@ -22,7 +22,7 @@ __device__ __forceinline__ v4i_t raw_rsrc(const void* base, uint32_t bytes) {
     return r;
 }
 
-template <int PIECES, int DMA>
+template <int PIECES, int DMA, int LPR = 4>       // LPR lanes per row: 64-byte (4), 128-byte (8) or 256-byte (16) contiguous segments
 __global__ __launch_bounds__(256, 3) void stage(const char* src, uint32_t src_bytes, int iters, uint32_t* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256, 3) void stage(const char* src, uint32_t src_by
     uint32_t cur[PIECES], dst[PIECES];
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) {
-        const int row = ((blockIdx.x * 4 + wave) * PIECES + i) * 16 + (lane >> 2);
-        cur[i] = (uint32_t)(((size_t)row * 2560 + (lane & 3) * 16) % (src_bytes - 4096));
+        const int row = ((blockIdx.x * 4 + wave) * PIECES + i) * (64 / LPR) + lane / LPR;
+        cur[i] = (uint32_t)(((size_t)row * 2560 + (lane % LPR) * 16) % (src_bytes - 4096));
         dst[i] = smem_base + ((wave * PIECES + i) % 48) * 1024;
     }
     uint32_t acc = 0;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256, 3) void stage(const char* src, uint32_t src_by
 #pragma unroll
         for (int i = DMA; i < PIECES; ++i) *reinterpret_cast<uint4*>(smem + (dst[i] - smem_base) + lane * 16) = r[i - DMA];
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) cur[i] = (cur[i] + 64) % (src_bytes - 4096);
+        for (int i = 0; i < PIECES; ++i) cur[i] = (cur[i] + LPR * 16) % (src_bytes - 4096);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         acc += *reinterpret_cast<const uint32_t*>(smem + ((tid * 16 + it * 64) & 49151));
@@ -63,10 +63,10 @@ __global__ __launch_bounds__(256, 3) void stage(const char* src, uint32_t src_by
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
-template <int PIECES, int DMA>
+template <int PIECES, int DMA, int LPR = 4>
 static void run(const char* src, uint32_t bytes, uint32_t* sink, int clock_mhz) {
     const int iters = 400, grid = 256 * 3;
-    auto k = stage<PIECES, DMA>;
+    auto k = stage<PIECES, DMA, LPR>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 48 * 1024);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -79,8 +79,8 @@ static void run(const char* src, uint32_t bytes, uint32_t* sink, int clock_mhz) 
     hipEventElapsedTime(&ms, e0, e1);
     const double bytes_per_cu = 3.0 * iters * 3 /*WG per CU*/ * 4 /*waves*/ * PIECES * 1024.0;
     const double us = ms * 1000.0;
-    printf("{\"pieces_per_wave\": %d, \"by_dma\": %d, \"by_registers\": %d, \"us\": %.1f, \"GB_per_s_per_cu\": %.1f, \"B_per_clk_per_cu_at_%dMHz\": %.1f}\n",
-           PIECES, DMA, PIECES - DMA, us, bytes_per_cu / us / 1e3, clock_mhz, bytes_per_cu / us / clock_mhz);
+    printf("{\"segment_bytes\": %d, \"pieces_per_wave\": %d, \"by_dma\": %d, \"by_registers\": %d, \"us\": %.1f, \"GB_per_s_per_cu\": %.1f, \"B_per_clk_per_cu_at_%dMHz\": %.1f}\n",
+           LPR * 16, PIECES, DMA, PIECES - DMA, us, bytes_per_cu / us / 1e3, clock_mhz, bytes_per_cu / us / clock_mhz);
 }
 
 int main() {
@@ -97,6 +97,7 @@ int main() {
     run<4, 4>(src, bytes, sink, clk); run<4, 0>(src, bytes, sink, clk); run<4, 2>(src, bytes, sink, clk); run<4, 3>(src, bytes, sink, clk); run<4, 1>(src, bytes, sink, clk);
     run<8, 8>(src, bytes, sink, clk); run<8, 0>(src, bytes, sink, clk); run<8, 4>(src, bytes, sink, clk); run<8, 6>(src, bytes, sink, clk); run<8, 5>(src, bytes, sink, clk);
     run<12, 12>(src, bytes, sink, clk); run<12, 8>(src, bytes, sink, clk); run<12, 6>(src, bytes, sink, clk);
+    run<8, 8, 8>(src, bytes, sink, clk); run<8, 0, 8>(src, bytes, sink, clk); run<8, 8, 16>(src, bytes, sink, clk); run<8, 0, 16>(src, bytes, sink, clk); run<8, 8, 2>(src, bytes, sink, clk); run<8, 8, 1>(src, bytes, sink, clk);
     }
     return 0;
 }
