@@ -450,7 +450,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 0: *bm = 128; *bn = 128; return 0;
         case 1: *bm = 128; *bn = 64; return 0;
         case 2: *bm = 64; *bn = 64; return 0;
-        case 4: case 5: case 8: *bm = 128; *bn = 128; return 0;
+        case 4: case 5: case 8: case 29: *bm = 128; *bn = 128; return 0;
         case 3: case 7: *bm = 64; *bn = 64; return 0;
         case 6: *bm = 64; *bn = 320; return 0;
         case 9: case 21: *bm = 256; *bn = 128; return 0;
@@ -485,11 +485,11 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
-    return cfg == 5 ? imd_conv_patch_stats_parts_of(p) : 0;
+    return (cfg == 5 || cfg == 29) ? imd_conv_patch_stats_parts_of(p) : 0;
 }
 
 int imd_conv_gemm_choose_cfg(int M, int N) {
@@ -584,6 +584,12 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         case 5: {   // LDS-resident halo patch (conv_patch.hip): 3x3 stride-1 only, optional fused GroupNorm prologue
             int rc = imd_launch_conv_patch(p, s);
             if (rc || p.split_k <= 1 || p.splitk_counters != nullptr) return rc;
+            return launch_splitk_finish(p, s, "conv_patch split-K finish");
+        }
+        case 29: {  // the halo-patch kernel with 64-channel chunks: 128-byte rows, i.e. whole L2 lines (conv_patch.hip)
+            p.splitk_counters = nullptr;
+            int rc = imd_launch_conv_patch64(p, s);
+            if (rc || p.split_k <= 1) return rc;
             return launch_splitk_finish(p, s, "conv_patch split-K finish");
         }
         case 21: {  // halo patch, 16 x 16 pixel tiles (conv_patch2.hip)

@@ -57,9 +57,27 @@ constexpr int W_VECS = BN * (CK / 8) / 256;             // 2
 constexpr int AB_D = 12 * 1024, WB_D = 8 * 1024, NWR_D = 3;
 constexpr int PATCH_DMA_LDS = 2 * AB_D + NWR_D * WB_D;            // 49,152 (>= EPI_LDS)
 static_assert(PATCH_DMA_LDS >= EPI_LDS, "the epilogue tile must fit the main-loop LDS");
+// CKD = 64 (tile config 29, round 4): 64-channel chunks = 128-BYTE rows.  The L2 hands a CU whole 128-byte lines (tools/probes/staging_probe.hip:
+// 62 GB/s per CU in 64-byte segments, 113 in 128-byte ones); the 64-byte rows above use half of every line they pull.  Patch 180 x 128 B (23 pieces,
+// six per wave with one empty), weight tile 128 x 128 B (16 pieces, four per wave), piece c of row r at c ^ ((r >> 1) & 7); 16 MFMAs per wave and
+// tap.  80 KB of LDS with a TWO-slot weight ring (the next tap's tile lands while this tap is multiplied) -> two workgroups per CU.
+template <int CKD> struct PD {
+    static constexpr int RB = CKD * 2, LPR = RB / 16;                       // row bytes, 16-byte pieces per row
+    static constexpr int APIECES = (NPIX * RB + 1023) / 1024;               // 12 | 23
+    static constexpr int APW = (APIECES + 3) / 4;                           // patch pieces per wave: 3 | 6
+    static constexpr int AB = APW * 4 * 1024;                               // 12,288 | 24,576
+    static constexpr int WPW = BN * RB / 1024 / 4;                          // weight pieces per wave and tap: 2 | 4
+    static constexpr int WB = WPW * 4 * 1024;                               // 8,192 | 16,384
+    static constexpr int NWR = CKD == 32 ? 3 : 2;
+    static constexpr int LDS = 2 * AB + NWR * WB;                           // 49,152 | 81,920
+    static_assert(LDS >= EPI_LDS, "the epilogue tile must fit the main-loop LDS");
+    static __device__ __forceinline__ int swz(int r) { return CKD == 32 ? (r >> 2) & 3 : (r >> 1) & 7; }
+};
 
-template <bool F16, bool DMA>
-__global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmParams p) {
+template <bool F16, bool DMA, int CKD = 32>
+__global__ __launch_bounds__(256, CKD == 32 ? 3 : 2) void conv3x3_patch_kernel(const ConvGemmParams p) {
+    static_assert(CKD == 32 || DMA, "64-channel chunks exist for the LDS-DMA form only");
+    using G = PD<CKD>;
     using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Abuf = smem;
@@ -86,7 +104,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
     const int b = bid / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW, n0 = tile_n * BN;
 
-    const int nchunks = p.Cin / CK;
+    const int nchunks = p.Cin / CKD;
     const int split = blockIdx.y;
     const int per = (nchunks + p.split_k - 1) / p.split_k;
     const int c_begin = split * per;
@@ -209,50 +227,50 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
         const uint32_t smem_base = (uint32_t)(uintptr_t)smem;
         const v4i_t dx = raw_rsrc(p.x, p.x_bytes), dw = raw_rsrc(p.w, p.w_bytes);
         constexpr uint32_t FAR = 0x80000000u;
-        uint32_t acur[3], wcur[2];            // running source offsets: patch pieces of the NEXT chunk to stage, weight pieces of the next tap
-        uint32_t adst[3], wdst[2];            // LDS byte addresses of the pieces inside patch buffer 0 / ring slot 0 (wave-uniform)
+        uint32_t acur[G::APW], wcur[G::WPW];  // running source offsets: patch pieces of the NEXT chunk to stage, weight pieces of the next tap
+        uint32_t adst[G::APW], wdst[G::WPW];  // LDS byte addresses of the pieces inside patch buffer 0 / ring slot 0 (wave-uniform)
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int slot = (wv * 3 + i) * 64 + lane, pp = slot >> 2, piece = (slot & 3) ^ ((pp >> 2) & 3);
+        for (int i = 0; i < G::APW; ++i) {
+            const int slot = (wv * G::APW + i) * 64 + lane, pp = slot / G::LPR, piece = (slot % G::LPR) ^ G::swz(pp);
             acur[i] = FAR;
             if (pp < NPIX) {
                 const int iy = y0 - 1 + pp / PW, ix = x0 - 1 + pp % PW;        // logical pixel; the zero halo is applied AFTER the upsample
                 if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
                     const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;     // nearest-2x: source pixel = logical pixel >> 1
-                    acur[i] = (uint32_t)(((b * p.Hin + sy) * p.Win + sx) * p.x_pix_stride + piece * 8 + c_begin * CK) * 2u;
+                    acur[i] = (uint32_t)(((b * p.Hin + sy) * p.Win + sx) * p.x_pix_stride + piece * 8 + c_begin * CKD) * 2u;
                 }
             }
-            adst[i] = smem_base + (uint32_t)((wv * 3 + i) * 1024);
+            adst[i] = smem_base + (uint32_t)((wv * G::APW + i) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int slot = (wv * 2 + i) * 64 + lane, row = slot >> 2, piece = (slot & 3) ^ ((row >> 2) & 3);
-            wcur[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8 + c_begin * CK) * 2) : FAR;
-            wdst[i] = smem_base + (uint32_t)(2 * AB_D + (wv * 2 + i) * 1024);
+        for (int i = 0; i < G::WPW; ++i) {
+            const int slot = (wv * G::WPW + i) * 64 + lane, row = slot / G::LPR, piece = (slot % G::LPR) ^ G::swz(row);
+            wcur[i] = (n0 + row < p.N) ? (uint32_t)(((size_t)(n0 + row) * p.K + piece * 8 + c_begin * CKD) * 2) : FAR;
+            wdst[i] = smem_base + (uint32_t)(2 * G::AB + (wv * G::WPW + i) * 1024);
         }
-        const uint32_t w_tap = (uint32_t)(p.Cin * 2), w_chunk = (uint32_t)(CK * 2) - 8u * w_tap;      // next tap / tap 8 -> tap 0 of the next chunk
+        const uint32_t w_tap = (uint32_t)(p.Cin * 2), w_chunk = (uint32_t)(CKD * 2) - 8u * w_tap;      // next tap / tap 8 -> tap 0 of the next chunk
         auto dma_patch = [&](auto buf_c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
+            for (int i = 0; i < G::APW; ++i) {
                 asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
-                             : : "v"(acur[i]), "s"(adst[i]), "s"(dx), "n"(decltype(buf_c)::value * AB_D) : "memory", "scc");
-                acur[i] += (uint32_t)(CK * 2);
+                             : : "v"(acur[i]), "s"(adst[i]), "s"(dx), "n"(decltype(buf_c)::value * G::AB) : "memory", "scc");
+                acur[i] += (uint32_t)(CKD * 2);
             }
         };
         auto dma_w = [&](auto ring_c, auto cross_c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < G::WPW; ++i) {
                 asm volatile("s_add_u32 m0, %1, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds"
-                             : : "v"(wcur[i]), "s"(wdst[i]), "s"(dw), "n"(decltype(ring_c)::value * WB_D) : "memory", "scc");
+                             : : "v"(wcur[i]), "s"(wdst[i]), "s"(dw), "n"(decltype(ring_c)::value * G::WB) : "memory", "scc");
                 wcur[i] += decltype(cross_c)::value ? w_chunk : w_tap;
             }
         };
         // fragment addresses (bytes inside a patch buffer / a ring slot), all loop-invariant
-        int w_fr[2], xa[9][2];            // 16-deep slice kk = 0; kk = 1 is the same address ^ 32 (one VALU in the loop instead of 20 more live registers)
+        int w_fr[2], xa[9][2];            // 16-deep slice kk = 0; slice kk is the same address ^ (kk << 5) (one VALU in the loop instead of more live registers)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int row = wn0 + a * 32 + col;
-            w_fr[a] = row * 64 + ((hi ^ ((row >> 2) & 3)) << 4);
+            w_fr[a] = row * G::RB + ((hi ^ G::swz(row)) << 4);
         }
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int rw = r0 + (t / 3) * PW + (t % 3);
-                xa[t][bb] = rw * 64 + ((hi ^ ((rw >> 2) & 3)) << 4);
+                xa[t][bb] = rw * G::RB + ((hi ^ G::swz(rw)) << 4);
             }
         }
         const bool live = __builtin_amdgcn_readfirstlane((int)(n0 + (wv & 1) * 64 < p.N)) != 0;      // scalar: the whole wave or nothing
@@ -268,40 +286,54 @@ __global__ __launch_bounds__(256, 3) void conv3x3_patch_kernel(const ConvGemmPar
         if (total > 0) {
             dma_patch(i0);
             dma_w(i0, std::false_type{});
-            dma_w(i1, std::false_type{});
+            if (G::NWR == 3) dma_w(i1, std::false_type{});
         }
         dma_wait();
         __syncthreads();
-        auto chunk = [&](auto ab_c) __attribute__((always_inline)) {       // one 32-channel chunk out of patch buffer ab_c
+        auto chunk = [&](auto ab_c) __attribute__((always_inline)) {       // one chunk out of patch buffer ab_c
             constexpr int AB = decltype(ab_c)::value;
-            const char* As = smem + AB * AB_D;
+            const char* As = smem + AB * G::AB;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {                  // 9 taps = 3 turns of the weight ring: ring slots are compile-time
-                if (t % 3 == 0) dma_w(i2, std::false_type{});
-                else if (t % 3 == 1) dma_w(i0, std::false_type{});
-                else dma_w(i1, std::false_type{});
-                if (t == 6) { wcur[0] += w_chunk - w_tap; wcur[1] += w_chunk - w_tap; }     // (the piece just staged was tap 8: the next one is tap 0 of the next chunk)
-                if (t == 5) dma_patch(std::integral_constant<int, AB ^ 1>{});              // (always 3 pieces: the counted waits rely on it)
-                if (live) {
-                    const char* Ws = smem + 2 * AB_D + (t % 3) * WB_D;
-                    uint4 wf[2][2], xf[2][2];
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                        for (int a = 0; a < 2; ++a) wf[kk][a] = *reinterpret_cast<const uint4*>(Ws + (w_fr[a] ^ (kk * 32)));
-#pragma unroll
-                        for (int bb = 0; bb < 2; ++bb) xf[kk][bb] = *reinterpret_cast<const uint4*>(As + (xa[t][bb] ^ (kk * 32)));
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int a = 0; a < 2; ++a)
-#pragma unroll
-                            for (int bb = 0; bb < 2; ++bb) acc[a][bb] = E::mfma(wf[kk][a], xf[kk][bb], acc[a][bb]);
+            for (int t = 0; t < 9; ++t) {                  // ring slots are compile-time: 9 taps = 3 turns of a three-slot ring; two slots alternate over a chunk PAIR
+                constexpr int LEAD = G::NWR - 1;           // the tile staged at tap t is tap t + LEAD's
+                const int cur = G::NWR == 3 ? t % 3 : (9 * AB + t) % 2;
+                if (G::NWR == 3) {
+                    if (t % 3 == 0) dma_w(i2, std::false_type{});
+                    else if (t % 3 == 1) dma_w(i0, std::false_type{});
+                    else dma_w(i1, std::false_type{});
+                } else {
+                    if (((9 * AB + t) & 1) == 0) dma_w(i1, std::false_type{}); else dma_w(i0, std::false_type{});
                 }
-                // the next tap's weight pieces have landed: everything but this tap's two pieces (and, at taps 5 and 6, the three
-                // patch pieces issued behind them at tap 5) may stay in flight
-                if (t == 5 || t == 6) dma_wait_keep5(); else dma_wait_keep2();
+                if (t == 8 - LEAD) {                       // (the piece just staged was tap 8: the next one is tap 0 of the next chunk)
+#pragma unroll
+                    for (int i = 0; i < G::WPW; ++i) wcur[i] += w_chunk - w_tap;
+                }
+                if (t == 5) dma_patch(std::integral_constant<int, AB ^ 1>{});              // (always APW pieces: the counted waits rely on it)
+                if (live) {
+                    const char* Ws = smem + 2 * G::AB + cur * G::WB;
+#pragma unroll
+                    for (int k2 = 0; k2 < CKD / 32; ++k2) {            // 32 channels at a time: eight fragment reads, eight MFMAs
+                        uint4 wf[2][2], xf[2][2];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) wf[kk][a] = *reinterpret_cast<const uint4*>(Ws + (w_fr[a] ^ ((2 * k2 + kk) * 32)));
+#pragma unroll
+                            for (int bb = 0; bb < 2; ++bb) xf[kk][bb] = *reinterpret_cast<const uint4*>(As + (xa[t][bb] ^ ((2 * k2 + kk) * 32)));
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                                for (int bb = 0; bb < 2; ++bb) acc[a][bb] = E::mfma(wf[kk][a], xf[kk][bb], acc[a][bb]);
+                    }
+                }
+                // the next tap's weight pieces have landed.  Three slots: everything but this tap's pieces (and, at taps 5 and 6, the patch pieces
+                // issued behind them at tap 5) may stay in flight.  Two slots: the next tap's tile is the one just staged -- only the patch pieces
+                // issued behind it at tap 5 may stay
+                if (G::NWR == 3) { if (t == 5 || t == 6) dma_wait_keep_n<G::WPW + G::APW>(); else dma_wait_keep_n<G::WPW>(); }
+                else { if (t == 5) dma_wait_keep_n<G::APW>(); else dma_wait(); }
                 __syncthreads();
             }
         };
@@ -484,6 +516,28 @@ bool imd_conv_patch_supported(const ConvGemmParams& p) {
                             : (p.Hin == p.Hout && p.Win == p.Wout);
     return p.taps == 9 && p.stride == 1 && !p.pad_br_only && geom && p.Hout >= TH && p.Wout >= TW && (p.Cin % CK) == 0 &&
            p.mode == OUT_ROWMAJOR && p.act != ACT_GEGLU;
+}
+
+// tile config 29: the LDS-DMA form with 64-channel chunks (128-byte rows)
+bool imd_conv_patch64_supported(const ConvGemmParams& p) {
+    return imd_conv_patch_supported(p) && (p.Cin % 64) == 0 && p.gn_a == nullptr && !(g_gemm_flags & 512) && p.x_bytes < 0x80000000u && p.w_bytes < 0x80000000u;
+}
+
+int imd_launch_conv_patch64(const ConvGemmParams& p, hipStream_t s) {
+    if (!imd_conv_patch64_supported(p)) return imd_set_error("conv_patch (128-byte rows): unsupported problem (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 64 == 0, operands < 2 GiB, no fused GroupNorm)");
+    static bool attr_set[2] = {false, false};
+    const bool h = p.dtype == IMD_DTYPE_F16;
+    typedef void (*kern_t)(const ConvGemmParams);
+    const kern_t kern = h ? conv3x3_patch_kernel<true, true, 64> : conv3x3_patch_kernel<false, true, 64>;
+    if (!attr_set[h]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PD<64>::LDS);
+        if (e != hipSuccess) return imd_set_error("conv_patch: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        attr_set[h] = true;
+    }
+    const int B = p.M / (p.Hout * p.Wout);
+    const long blocks = (long)B * ((p.Hout + TH - 1) / TH) * ((p.Wout + TW - 1) / TW) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PD<64>::LDS, s, p);
+    return imd_check_launch("conv_patch (128-byte rows)");
 }
 
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {

@@ -32,6 +32,8 @@ int imd_launch_conv_patch3(const ConvGemmParams& p, hipStream_t s);
 bool imd_conv_patch4_supported(const ConvGemmParams& p);      // conv_patch3.hip with eight waves: 16 x 16 pixels x 160 channels (tile config 23)
 int imd_launch_conv_patch4(const ConvGemmParams& p, hipStream_t s);
 int imd_conv_patch3_stats_parts_of(const ConvGemmParams& p, int nw);
+bool imd_conv_patch64_supported(const ConvGemmParams& p);    // conv_patch.hip with 64-channel chunks = 128-byte rows (tile config 29)
+int imd_launch_conv_patch64(const ConvGemmParams& p, hipStream_t s);
 bool imd_conv_img_supported(const ConvGemmParams& p);         // conv_img.hip: whole 8-wide maps x 64 channels x one K slice per workgroup (tile config 24)
 int imd_launch_conv_img(const ConvGemmParams& p, hipStream_t s);
 int imd_conv_patch_stats_parts_of(const ConvGemmParams& p);

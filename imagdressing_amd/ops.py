@@ -286,7 +286,7 @@ def conv_gemm(
         if SPLITK_IN_KERNEL:
             p.splitk_counters = splitk_counters(x.device).data_ptr()
     stats = None
-    if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and (cfg in (5, 22, 23) or split_k > 1):
+    if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and (cfg in (5, 22, 23, 29) or split_k > 1):
         p.gn_stats_groups = gn_stats_groups
         nparts = lib.imd_conv_gemm_stats_parts(C.byref(p), cfg)       # halo-patch epilogue (un-split) or the finish launch of the K slices
         if nparts > 0:

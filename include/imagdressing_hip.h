@@ -209,6 +209,8 @@ int imd_device_check(int device);
  * 23: 22 with eight waves = 16 x 16 pixels x 160 channels per workgroup (one staged weight tile serves 256 pixels: 154 instead of 290 bytes of LDS-DMA per MFMA).
  * 25 / 27: the 128 x 128 LDS-DMA tiles of 17 / 19 with 128-BYTE rows (K tile 64), two / three ring stages: the L2 hands a CU whole 128-byte lines, 64-byte
  *     rows use half of each (tools/probes/staging_probe.hip); 26 / 28: the 3x3 gathering form of the same (one tap x 64 channels per tile, Cin % 64 == 0).
+ * 29: the halo-patch kernel (5) with 64-channel chunks = 128-byte rows and a two-slot weight ring (80 KB of LDS, two workgroups per CU): measured slower
+ *     than 5 on every shape of the UNet (the ring and the third workgroup matter more than the whole lines), kept as a tuning candidate.
  * 24: 3x3 stride-1 convolutions of maps 8 pixels wide (the UNet's lowest level): a workgroup owns all pixels of up to 8 images x 64 channels x one
  *     K slice, so every weight byte is fetched once; K-sliced only (split_k >= 2).
  * Results are identical up to fp32 summation order. */

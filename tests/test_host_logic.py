@@ -405,7 +405,7 @@ def test_tuning_table_only_names_known_tile_configs():
             Ho, Wo = map(int, geom.split("x"))
             assert taps == 9 and M % (Ho * Wo) == 0, key
         for c in (ent["cfg"], ent["cfg_nosplit"]):
-            assert c in range(0, 29), (key, ent)
+            assert c in range(0, 30), (key, ent)
             if c in (17, 19, 25, 27): assert K % 64 == 0 and taps == 1, key
             if c in (18, 20): assert taps == 9 and (K // 9) % 32 == 0, key
             if c in (26, 28): assert taps == 9 and (K // 9) % 64 == 0, key
@@ -414,7 +414,8 @@ def test_tuning_table_only_names_known_tile_configs():
             if c == 14: assert K == 1280 and N % 160 == 0 and taps == 1, key
             if c == 15: assert K == 320 and N == 960 and taps == 1, key
             if c == 16: assert K % 64 == 0 and taps == 1, key
-            if c in (5, 21, 22, 23):
+            if c == 29: assert taps == 9 and stride == 1 and (K // 9) % 64 == 0, key
+            if c in (5, 21, 22, 23, 29):
                 assert taps == 9 and stride == 1, key
                 if geom: assert Wo >= 16 and Ho >= 8, key          # the halo-patch kernel's 8 x 16 pixel tiles
             if c == 24:

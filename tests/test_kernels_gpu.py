@@ -425,6 +425,46 @@ def test_conv3x3_dma_gather_split_k(ops, B, H, W, Cin, Cout, stride, split, dt, 
     assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), stride=stride, res=dev(res), cfg=cfg, split_k=split)), "not deterministic"
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,split,ups", [
+    (1, 32, 32, 320, 320, 1, False),      # five 64-channel chunks (odd: the two-slot weight ring ends on the other slot), N = 320: half-empty last channel tile
+    (2, 16, 16, 640, 256, 2, False), (1, 8, 16, 1280, 128, 4, False), (1, 96, 72, 320, 320, 1, False), (2, 9, 17, 64, 40, 1, False),
+    (1, 16, 16, 128, 136, 1, True), (1, 24, 16, 192, 132, 3, False)])
+@DTS
+def test_conv3x3_halo_patch_128_byte_rows(ops, B, H, W, Cin, Cout, split, ups, dt):
+    """tile config 29 (conv_patch.hip with 64-channel chunks: 128-byte rows, two-slot weight ring, two workgroups per CU) == F.conv2d with the full
+    epilogue, K slices, ragged maps and the fused upsample; close to the 32-channel-chunk kernel (the K order inside a tap differs), the GroupNorm
+    statistics of the un-split epilogue included"""
+    x = rnd(1, B, Cin, H, W).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    b = rnd(3, Cout); temb = rnd(4, B, Cout); res = rnd(5, B, Ho, Wo, Cout).to(dt)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), b, padding=1).permute(0, 2, 3, 1) + temb[:, None, None, :] + res.float()
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    kw = dict(rowvec=dev(temb), rowvec_stride=Cout, res=dev(res), ups=ups, split_k=split)
+    out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=29, **kw)
+    assert tuple(out.shape) == (B, Ho, Wo, Cout)
+    assert_close(out, ref, what=f"halo-patch conv, 128-byte rows, split={split} ups={ups}")
+    assert_close(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=5, **kw).float(), atol=2e-2 if dt == bf16 else 4e-3, what="vs 64-byte rows")
+    assert torch.equal(out, ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=29, **kw)), "not deterministic"
+    if Cout % 32 == 0 and Cout // 32 >= 8:
+        st_out = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), cfg=29, gn_stats_groups=32, **kw)
+        assert torch.equal(st_out, out)
+        st = getattr(st_out, "_imd_gn_stats", None)
+        assert st is not None
+        folded = st[0].double().sum(1).cpu()
+        o = out.double().cpu().permute(0, 3, 1, 2).reshape(B, 32, -1)
+        assert torch.allclose(folded[..., 0] / o.shape[-1], o.mean(-1), atol=1e-4)
+    if Cin % 64:
+        pytest.fail("unreachable: every case has Cin % 64 == 0")
+
+
+def test_conv3x3_halo_patch_128_byte_rows_refuses_other_chunks(ops):
+    x = rnd(1, 1, 96, 8, 16).to(bf16); w = rnd(2, 64, 96, 3, 3).to(bf16)
+    with pytest.raises(ops.L.ImdError):
+        ops.conv2d_nhwc(dev(x.permute(0, 2, 3, 1).contiguous()), dev(pack_conv(w)), None, cfg=29)        # Cin % 64 != 0
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,split", [(1, 8, 8, 64, 64, 1), (2, 16, 16, 640, 640, 2), (1, 12, 18, 32, 320, 1), (2, 32, 32, 320, 132, 1)])
 @DTS
 def test_conv3x3_halo_patch_fused_upsample(ops, B, H, W, Cin, Cout, split, dt):
