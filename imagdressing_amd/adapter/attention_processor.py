@@ -620,38 +620,84 @@ class BaseSAttnProcessor2_0(nn.Module, _FusedBase):
 
 
 class SAttnProcessor2_0(nn.Module, _FusedBase):
-    """Concat-KV variant (attention_processor.py:103-199, ONE softmax over [self; garment] keys, :157-159).
-    Unused by every reference entry point; kept importable, executes plain self-attention when no
-    garment tokens are passed and refuses the concat form (different arithmetic from the hybrid)."""
+    """Concat-KV variant (attention_processor.py:103-199): ONE softmax over the keys of ``cat([hidden_states, garment tokens])``
+    (:154-159), both through the layer's own to_k / to_v.  Unused by every reference entry point; here it is one phase of the fused
+    attention kernel over concatenated K / V^T buffers: the garment half is projected once per garment and cached, the image half is
+    projected per call, and the two are laid side by side (copies, no arithmetic) in front of the launch."""
 
     def __init__(self, name, hidden_size, cross_attention_dim=None):
         super().__init__()
         self.name, self.hidden_size, self.cross_attention_dim = name, hidden_size, cross_attention_dim
         self._plain = AttnProcessor2_0(cache_entries=4)
-
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
-                 sa_hidden_states=None, imd_residual=None, **kwargs):
-        if sa_hidden_states is not None:
-            raise NotImplementedError("SAttnProcessor2_0 (single softmax over concatenated keys) is legacy and unused; "
-                                      "use RefSAttnProcessor2_0")
-        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
-
-
-class RefCAttnProcessor2_0(nn.Module, _FusedBase):
-    """Legacy cross-attention + garment-token variant (attention_processor.py:630-743); unused by the reference's
-    entry points.  Parameters are kept for checkpoint compatibility; it executes as text cross-attention and
-    refuses the garment form."""
-
-    def __init__(self, name, hidden_size, cross_attention_dim=None, scale=1.0):
-        super().__init__()
-        self.name, self.hidden_size, self.cross_attention_dim = name, hidden_size, cross_attention_dim
-        self.to_k_ref = nn.Linear(hidden_size, hidden_size, bias=False)
-        self.to_v_ref = nn.Linear(hidden_size, hidden_size, bias=False)
-        self.scale = scale
-        self._plain = AttnProcessor2_0(cache_entries=4)
+        self._garment = _TensorCache()
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  cond_hidden_states=None, sa_hidden_states=None, imd_residual=None, **kwargs):
-        if cond_hidden_states is not None:
-            raise NotImplementedError("RefCAttnProcessor2_0's garment form is legacy and unused; use RefSAttnProcessor2_0 on attn1")
-        return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
+        if sa_hidden_states is None or encoder_hidden_states is not None:        # (:152-160: the garment form exists for self-attention only)
+            return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
+        dt = _compute_dtype(attn, hidden_states, attention_mask)
+        x, shape4 = _as_tokens(hidden_states, dt)
+        dev, heads = x.device, attn.heads
+        B, N, Cc = x.shape
+        D = Cc // heads
+        ref = sa_hidden_states[self.name]
+        if ref.dim() != 3 or B % ref.shape[0]:
+            raise ValueError(f"sa_hidden_states[{self.name!r}] must be [Bg, M, C] with Bg dividing the batch {B}, got {tuple(ref.shape)}")
+        wkv = _layer_weights(attn, "kv", dt, dev)
+        srcs = (ref, attn.to_k.weight, attn.to_v.weight)
+        kvr = self._garment.get(srcs, extra=(dt,))
+        if kvr is None:
+            kvr = self._garment.put(srcs, _project_kv(ref.detach().to(device=dev, dtype=dt).contiguous(), wkv, heads), extra=(dt,))
+        kx, vtx, _, _ = _project_kv(x, wkv, heads)
+        M = kvr[2]
+        L, LP = N + M, ops.pad64(N + M)
+        dpk, dpv = ops.attn_padded_dims(D)
+        k = ops.k_buffer((B, heads, L, dpk), D, dt, dev)
+        vt = torch.zeros(B, heads, dpv, LP, dtype=dt, device=dev)
+        rep = B // ref.shape[0]
+        k[:, :, :N] = kx
+        k[:, :, N:] = kvr[0].repeat_interleave(rep, 0) if rep > 1 else kvr[0]
+        vt[..., :N] = vtx[..., :N]
+        vt[..., N:L] = (kvr[1].repeat_interleave(rep, 0) if rep > 1 else kvr[1])[..., :M]
+        out = _fused_attention(x, heads, wq_or_qkv=_layer_weights(attn, "q", dt, dev), self_attn=False, kv1=(k, vt, L, LP), kv1_bdiv=1,
+                               wo=_layer_weights(attn, "o", dt, dev), bo=_layer_weights(attn, "bo", dt, dev), residual=imd_residual)
+        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)
+
+
+class RefCAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
+    """Cross-attention + garment-token variant (attention_processor.py:630-743); unused by the reference's entry points.  Text (or,
+    without ``encoder_hidden_states``, self) attention plus a second softmax over the garment tokens through to_k_ref / to_v_ref,
+    added with ``self.scale`` -- the hybrid kernel's two phases with the text K / V as the first key set."""
+
+    def __init__(self, name, hidden_size, cross_attention_dim=None, scale=1.0):
+        super().__init__()
+        self._init_ref(name, hidden_size, None, scale)          # to_k_ref / to_v_ref are hidden_size x hidden_size here (:644-645)
+        self.cross_attention_dim = cross_attention_dim
+        self._plain = AttnProcessor2_0(cache_entries=4)
+        self._text = _TensorCache()
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
+                 cond_hidden_states=None, sa_hidden_states=None, sa_batch_mask=None, imd_residual=None, **kwargs):
+        if sa_hidden_states is None:                                               # :706 not taken
+            return self._plain(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, imd_residual=imd_residual)
+        dt = _compute_dtype(attn, hidden_states, attention_mask)
+        x, shape4 = _as_tokens(hidden_states, dt)
+        dev, heads = x.device, attn.heads
+        ref = sa_hidden_states[self.name]
+        kv2 = self._garment_kv(ref, heads, dev, dt)
+        bdiv2 = self._garment_bdiv(x.shape[0], ref)
+        s2 = self._branch_weights(x.shape[0], sa_batch_mask, dev)
+        wo, bo = _layer_weights(attn, "o", dt, dev), _layer_weights(attn, "bo", dt, dev)
+        if encoder_hidden_states is None:                                          # :681-682
+            out = _fused_attention(x, heads, wq_or_qkv=_layer_weights(attn, "qkv", dt, dev), self_attn=True, kv2=kv2, kv2_bdiv=bdiv2,
+                                   scale2=s2, wo=wo, bo=bo, residual=imd_residual)
+        else:
+            srcs = (encoder_hidden_states, attn.to_k.weight, attn.to_v.weight)
+            kv = self._text.get(srcs, extra=(dt,))
+            if kv is None:
+                e = encoder_hidden_states.to(device=dev, dtype=dt).contiguous()
+                kv = self._text.put(srcs, _project_kv(e, _layer_weights(attn, "kv", dt, dev), heads), extra=(dt,))
+            out = _fused_attention(x, heads, wq_or_qkv=_layer_weights(attn, "q", dt, dev), self_attn=False, kv1=kv,
+                                   kv1_bdiv=self._ehs_bdiv(x.shape[0], encoder_hidden_states), kv2=kv2, kv2_bdiv=bdiv2, scale2=s2,
+                                   wo=wo, bo=bo, residual=imd_residual)
+        return self._finish(attn, out, imd_residual is not None, hidden_states, shape4)

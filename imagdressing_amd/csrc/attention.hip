@@ -444,8 +444,9 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
 
 // head-dim-40 kernel variant (tuning knob 0, imd_set_tuning(0, v)); all variants give the same result up to fp32 order:
 //   13 (default): 12 with the overflow test of the deferred maximum only on the first and last steps of a phase and a check of the
-//      softmax denominators when the phase is done (a workgroup that finds one not finite runs again as variant 12); bf16 only,
-//      fp16 operands and the fused out-projection run 12;  12: 10 with the main loop unrolled over the three ring slots
+//      softmax denominators when the phase is done (a workgroup that finds one not finite runs again as variant 12); fp16
+//      operands (round 5) with the phase's reference maximum biased by 2^4 so that P = inf needs a score 20 base-2 units above the first
+//      block's maximum; the fused out-projection runs 12;  12: 10 with the main loop unrolled over the three ring slots
 //      (compile-time LDS addresses, three-instruction staging pieces) and the order inside every MFMA slot pinned;
 //   10 (the round-3 default): attention_d40.hip, software-pipelined steps with the MFMA / VALU interleave written out (N >= 512; shorter
 //      sequences and the causal mask fall through to variant 4 below), head-dim rows 32..40 of P.V on v_mfma_f32_16x16x32,

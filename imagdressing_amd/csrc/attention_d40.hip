@@ -227,6 +227,12 @@ __device__ __attribute__((always_inline)) bool attn40_body(const AttnParams& p) 
     // MFMA + VALU + LDS + DMA mix costs in isolation; what is left above that is scalar / address bookkeeping like this.
     constexpr bool STAT = (VAR & 2097152) != 0;
     constexpr bool UNCHK = (VAR & 4194304) != 0;          // (with STAT) interior steps without the overflow test: experiment, see variant 13
+    // fp16 under UNCHK (round 5): the phase's reference maximum is the first block's maximum PLUS this bias, i.e. P = 2^(s - m_first - 4):
+    // the first block's largest P is 2^-4 and fp16's 65504 is reached only by a score 20 base-2 units (a factor 10^6 in weight) above the
+    // first 32 keys' maximum -- the end-of-phase denominator test (inf / NaN) then re-runs the workgroup checked.  The price is at the
+    // other end: P below 2^-14 is an fp16 subnormal (the MFMA keeps subnormal inputs, tools/probes/mfma_subnormal_probe.hip), below
+    // 2^-25 it is 0 -- keys more than 21 units below the first maximum (weight < 5e-7 each) instead of 25 in the checked kernel.
+    constexpr float FIRST_BIAS = (F16 && UNCHK) ? 4.0f : 0.0f;
     static_assert(!STAT || ((VAR & 128) && (VAR & 8192) && !(VAR & 32768)), "the static-ring loop exists for the 4-wave LDS-DMA kernel with the 16x16x32 tail");
     static_assert(!PROJ || (TAIL && !(VAR & 32768)), "the fused out-projection lives in the 4-wave kernel with the 16x16x32 tail");
     constexpr int NW = (VAR & 32768) ? 8 : 4;              // waves per workgroup
@@ -628,7 +634,7 @@ __device__ __attribute__((always_inline)) bool attn40_body(const AttnParams& p) 
                     mx = fmaxf(mx, __shfl_xor(mx, 32));
                     const bool first = (j == 0);
                     if (first || __any(mx > OFFS_THR)) {
-                        const float want = m_ref[qb] + (first ? mx : fmaxf(mx, 0.f));
+                        const float want = m_ref[qb] + (first ? mx + FIRST_BIAS : fmaxf(mx, 0.f));
                         const float nref = E::tof(E::fromf(want));          // what the 16-bit Q slot can carry
                         const float delta = nref - m_ref[qb];
                         if (!first) {       // on the first block O is still 0 (and delta may be hugely negative: 2^-delta = inf)
@@ -1040,8 +1046,9 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
                 return h ? launch_attn40<true, 8, 1 | 8192>(p, s) : launch_attn40<false, 8, 1 | 8192>(p, s);
             }
             [[fallthrough]];
-        case 13:            // round 4 (default): 12 without the per-step overflow test on interior steps; bf16 only (fp16's P = 2^(s - m_ref) overflows at 2^16: real data gets there)
-            if (p.proj_w == nullptr && p.k_pad_one && !h) return launch_attn40<false, 8, 1 | 128 | 8192 | 2097152 | 4194304>(p, s);
+        case 13:            // round 4 (default): 12 without the per-step overflow test on interior steps; fp16 (round 5) with the reference maximum biased by 2^4 (FIRST_BIAS)
+            if (p.proj_w == nullptr && p.k_pad_one)
+                return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 2097152 | 4194304>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 2097152 | 4194304>(p, s);
             [[fallthrough]];
         case 12:            // round 4: the LDS-DMA kernel with the main loop unrolled over the three ring slots -- compile-time LDS
         default:            // addresses, three-instruction staging pieces, no first / ragged-block test on interior steps

@@ -2,7 +2,7 @@
 (``/root/reference/adapter/attention_processor.py`` and ``adapter/resampler.py``, imported
 verbatim through ``oracle/ref_loader.py``) on seeded fp32 inputs (TEST INFRASTRUCTURE).
 
-Run in the build container only:   python -m oracle.make_golden [base|full|geometry|unet|all]
+Run in the build container only:   python -m oracle.make_golden [base|full|geometry|legacy|unet|timesteps|all|trajectory [case ...]]
 The fixtures pin ``oracle/processors.py`` and ``oracle/resampler.py`` (tests/test_oracle_golden.py)
 and are what the ``-m gpu`` parity tests compare the HIP path with when /root/reference is absent.
 
@@ -309,6 +309,55 @@ def main_geometry():
 
 
 @torch.no_grad()
+def legacy_case(ap, kind, seed, B, N, M, C, heads, T=0, KD=0, scale=0.9, keep_rows=0):
+    """``SAttnProcessor2_0`` (kind "sattn": one softmax over [self; garment] keys) / ``RefCAttnProcessor2_0`` (kind "refc": text
+    cross-attention + garment softmax) of the reference, run per sample (their ``view(batch_size, ...)`` / ``cat`` need B == 1 with
+    a [1, M, C] garment).  Seeded: inputs are regenerated by tests (tests/cases.py::legacy_inputs)."""
+    kd = KD or C
+    w = attn_weights(seed, C, kd)
+    attn = make_attn(w, C, kd, heads)
+    x = seeded(seed + 20, B, N, C)
+    ref = seeded(seed + 21, 1, M, C)
+    ehs = seeded(seed + 24, B, T, KD, scale=0.5) if T else None
+    name = "blk.attn.processor"
+    wkr = wvr = None
+    if kind == "sattn":
+        proc = ap.SAttnProcessor2_0(name, C)
+        run = lambda xb, eb, sa: proc(attn, xb, sa_hidden_states=sa)          # noqa: E731
+    else:
+        proc = ap.RefCAttnProcessor2_0(name, C, KD or None, scale=scale)
+        wkr, wvr = seeded(seed + 22, C, C, scale=C ** -0.5), seeded(seed + 23, C, C, scale=C ** -0.5)
+        proc.to_k_ref.weight.copy_(wkr); proc.to_v_ref.weight.copy_(wvr)
+        run = lambda xb, eb, sa: proc(attn, xb, encoder_hidden_states=eb, sa_hidden_states=sa)     # noqa: E731
+    cond = torch.cat([run(x[b:b + 1], None if ehs is None else ehs[b:b + 1], {name: ref}) for b in range(B)])
+    plain = torch.cat([run(x[b:b + 1], None if ehs is None else ehs[b:b + 1], None) for b in range(B)])
+    rows = None
+    if keep_rows:
+        import numpy as np
+        rows = torch.from_numpy(np.sort(np.random.default_rng(seed + 99).choice(N, keep_rows, replace=False)))
+        cond, plain = cond[:, rows].clone(), plain[:, rows].clone()
+    return dict(kind=kind, seed=seed, B=B, N=N, M=M, C=C, heads=heads, T=T, KD=KD, scale=scale, out_garment=cond, out_plain=plain, rows=rows,
+                digests=dict(x=digest(x), ref=digest(ref), wq=digest(w["wq"]), ehs=None if ehs is None else digest(ehs)))
+
+
+def main_legacy():
+    """Seventh fixture file: the two processor classes no reference entry point installs but the module exports
+    (attention_processor.py:103-199, :630-743), in their garment forms."""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ap, _ = load_reference_adapter()
+    cases = {
+        "sattn_d40": legacy_case(ap, "sattn", 6000, B=2, N=200, M=330, C=320, heads=8),
+        "sattn_d40_n640": legacy_case(ap, "sattn", 6100, B=1, N=640, M=700, C=320, heads=8, keep_rows=256),     # N >= 512: the pipelined d = 40 kernel
+        "sattn_d160": legacy_case(ap, "sattn", 6200, B=1, N=64, M=80, C=1280, heads=8),
+        "refc_d40": legacy_case(ap, "refc", 6300, B=2, N=130, M=96, C=320, heads=8, T=77, KD=768),
+        "refc_d80_self": legacy_case(ap, "refc", 6400, B=1, N=144, M=100, C=640, heads=8, scale=0.8),           # encoder_hidden_states None (:681-682)
+    }
+    torch.save(cases, os.path.join(OUT, "processors_legacy.pt"))
+    print("processors_legacy.pt", os.path.getsize(os.path.join(OUT, "processors_legacy.pt")) // 1024, "KiB")
+
+
+@torch.no_grad()
 def main_unet():
     """Fourth fixture file: ONE full-width (859.5 M parameters) SD1.5 UNet forward of the fp32 oracle (oracle/sd15.py -- the
     restated, UNPINNED diffusers-0.24 UNet -- carrying oracle/processors.py, which IS pinned on the reference source) at
@@ -411,6 +460,89 @@ def main_timesteps():
     print("unet_forward_timesteps.pt", os.path.getsize(os.path.join(OUT, "unet_forward_timesteps.pt")) // 1024, "KiB")
 
 
+@torch.no_grad()
+def main_trajectory(which=None):
+    """Sixth fixture file (tests/golden/trajectory.pt): the reference's sampling loop END TO END (oracle/pipeline.py::denoise restating
+    IMAGDressing_v1_pipeline.py:463-541, ..._ipa_controlnet.py:595-736, ..._controlnet_inpainting.py:387-517) on the full-width fp32
+    oracle: Resampler (pinned) -> garment UNet pass at t = 0 -> every DDIM step with the two batch-1 UNet calls and the custom CFG ->
+    final latent, one image at a time.  Cases and seeds: tests/trajectory_fixture.py::CASES (BASELINE configs[0] 20 steps, configs[1]
+    50 steps x seeds 42 / 43, configs[2] and configs[4] 10 steps).  Stored: the final latent and the latents after a few steps
+    (64 KB each) plus input digests; the GPU tests and bench.py's ``parity.trajectory`` leg rebuild the inputs from seeds.
+    oracle/sd15.py + ddim.py are the UNPINNED restatement of diffusers 0.24; processors / resampler are pinned on the reference."""
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from imagdressing_amd import unet as E
+    from tests.harness_names import hidden_size_of
+    from tests.trajectory_fixture import CASES, FILE, initial_latents, trajectory_inputs
+    from tests.unet_fixture import fill_ipa_processors
+    from . import processors as OP
+    from . import sd15
+    from .ddim import DDIMOracle
+    from .pipeline import denoise
+    from .resampler import resampler_forward
+    torch.set_num_threads(8)
+    boc = E.SD15_CONFIG["block_out_channels"]
+    out = torch.load(FILE, weights_only=False) if os.path.isfile(FILE) else {}
+    built = {}
+    for name, spec in CASES.items():
+        if which and name not in which:
+            continue
+        kind, lh, lw = spec["kind"], spec["lh"], spec["lw"]
+        key = (kind, lh, lw)
+        if key not in built:
+            built.clear()
+            d = trajectory_inputs(kind, lh, lw)
+            o = sd15.UNet2DConditionModel({}); o.load_state_dict(d["sd"], strict=True)
+            r = sd15.UNet2DConditionModel({}); r.load_state_dict(d["sd_ref"], strict=True)
+            r.set_attn_processor({n: OP.CacheAttn() for n in r.attn_processors.keys()})
+            if kind == "ipa_controlnet":
+                procs = {n: (OP.LoraRefSAttn(n, hidden_size_of(n, boc), scale=d["ref_scale"], rank=d["rank"], lora_scale=d["lora_scale"])
+                             if n.endswith("attn1.processor") else
+                             OP.LoRAIPAttn(hidden_size_of(n, boc), 768, rank=d["rank"], lora_scale=d["lora_scale"], scale=d["ip_scale"], num_tokens=4))
+                         for n in o.attn_processors.keys()}
+                fill_ipa_processors(procs, d)
+            else:
+                procs = {n: (OP.RefSAttn(n, hidden_size_of(n, boc)) if n.endswith("attn1.processor")
+                             else OP.CAttn(n, hidden_size_of(n, boc), 768)) for n in o.attn_processors.keys()}
+                for n in d["names"]:
+                    procs[n].to_k_ref.weight.copy_(d["rw"][n]["k"]); procs[n].to_v_ref.weight.copy_(d["rw"][n]["v"])
+            o.set_attn_processor(procs)
+            c = None
+            if kind != "refs":
+                c = sd15.ControlNetModel({}); c.load_state_dict(d["ctrl_sd"], strict=True)
+            built[key] = (d, o, r, c)
+        d, o, r, c = built[key]
+        rsd = d["resampler_sd"]
+        cloth = torch.cat([resampler_forward(rsd, torch.zeros_like(d["clip"]), 12), resampler_forward(rsd, d["clip"], 12)])   # [null; proj] (:409-433)
+        lat = initial_latents(spec["seeds"], lh, lw)
+        finals, kept = [], {k: [] for k in spec["keep"]}
+        for si, seed in enumerate(spec["seeds"]):
+            t0 = time.time()
+            trace = []
+            kw = {}
+            pe, ne = d["pe"], d["ne"]
+            if kind == "ipa_controlnet":
+                pe, ne = d["ehs_c"], d["ehs_u"]
+                kw = dict(controlnet=c, control_image=d["pose"], prompt_embeds_control=torch.cat([d["ne"], d["pe"]]),
+                          conditioning_scale=spec["conditioning_scale"])
+            elif kind == "inpaint":
+                kw = dict(controlnet=c, control_image=d["control_image"], prompt_embeds_control=torch.cat([d["ne"], d["pe"]]),
+                          conditioning_scale=spec["conditioning_scale"],
+                          inpaint=dict(mask=d["mask"], image_latents=d["img_lat"], noise=lat[si:si + 1]))
+            fin = denoise(o, r, DDIMOracle(), lat[si:si + 1], pe, ne, cloth, d["refl"], spec["steps"], spec["guidance"], trace=trace, **kw)
+            finals.append(fin.clone())
+            for k in spec["keep"]:
+                kept[k].append(trace[k].clone())
+            print(name, "seed", seed, "final std", fin.std().item(), "finite", bool(torch.isfinite(fin).all()), f"{time.time() - t0:.0f} s", flush=True)
+        out[name] = dict(kind="trajectory", spec=dict(spec), final=torch.cat(finals), steps={k: torch.cat(v) for k, v in kept.items()},
+                         digests=d["traj_digests"], torch_version=torch.__version__)
+        torch.save(out, FILE)
+    print("trajectory.pt", os.path.getsize(FILE) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     import sys
     what = sys.argv[1] if len(sys.argv) > 1 else "all"          # base | full | geometry | unet | timesteps | all
@@ -420,7 +552,11 @@ if __name__ == "__main__":
         main_full()
     if what in ("geometry", "all"):
         main_geometry()
+    if what in ("legacy", "all"):
+        main_legacy()
     if what in ("unet", "all"):
         main_unet()
     if what in ("timesteps", "all"):
         main_timesteps()
+    if what == "trajectory":          # ~30 min of 8 cores; not part of "all"
+        main_trajectory(sys.argv[2:] or None)

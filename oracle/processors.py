@@ -100,6 +100,27 @@ def ip_cross_attention(
     return h @ wo.t() + bo + lora_scale * lora_delta(h, *lo)    # :859
 
 
+def concat_self_attention(x, wq, wk, wv, wo, bo, heads, ref=None):
+    """``SAttnProcessor2_0.__call__`` (attention_processor.py:119-199): ONE softmax over the keys of
+    ``cat([hidden_states, sa_hidden_states[name]], dim=1)`` (:154-159), K / V of both through the layer's own to_k / to_v
+    (:164-165).  ref [1, M, C] is broadcast over the batch (batched generation = independent B = 1 runs)."""
+    ehs = x if ref is None else torch.cat([x, ref.expand(x.shape[0], -1, -1)], dim=1)
+    return sdpa(x @ wq.t(), ehs @ wk.t(), ehs @ wv.t(), heads) @ wo.t() + bo
+
+
+def cross_plus_garment_attention(x, ehs, wq, wk, wv, wo, bo, heads, ref=None, wk_ref=None, wv_ref=None, scale=1.0):
+    """``RefCAttnProcessor2_0.__call__`` (attention_processor.py:649-743): text cross-attention (:681-704; self-attention when
+    ``encoder_hidden_states`` is None, :681-682) plus, when ``sa_hidden_states`` is given (:706), a second softmax over the garment
+    tokens through to_k_ref / to_v_ref added with ``self.scale`` (:709-722)."""
+    q = x @ wq.t()
+    e = x if ehs is None else ehs
+    h = sdpa(q, e @ wk.t(), e @ wv.t(), heads)
+    if ref is not None:
+        r = ref.expand(x.shape[0], -1, -1)
+        h = h + sdpa(q, r @ wk_ref.t(), r @ wv_ref.t(), heads) * scale
+    return h @ wo.t() + bo
+
+
 # --------------------------------------------------------------------------------------
 # AttnProcessor-protocol wrappers over the functions above, so the oracle UNet
 # (oracle/sd15.py) can run the reference's loop semantics on hosts where /root/reference is

@@ -49,6 +49,23 @@ def cross_inputs(c):
     return d
 
 
+def legacy_inputs(c):
+    """Inputs of a tests/golden/processors_legacy.pt case (oracle/make_golden.py::legacy_case)."""
+    s, C = c["seed"], c["C"]
+    kd = c["KD"] or C
+    d = attn_weights(s, C, kd)
+    d["x"] = seeded(s + 20, c["B"], c["N"], C)
+    d["ref"] = seeded(s + 21, 1, c["M"], C)
+    d["ehs"] = seeded(s + 24, c["B"], c["T"], c["KD"], scale=0.5) if c["T"] else None
+    d["wk_ref"] = d["wv_ref"] = None
+    if c["kind"] == "refc":
+        d["wk_ref"] = seeded(s + 22, C, C, scale=C ** -0.5)
+        d["wv_ref"] = seeded(s + 23, C, C, scale=C ** -0.5)
+    assert digest(d["x"]) == c["digests"]["x"] and digest(d["ref"]) == c["digests"]["ref"] and digest(d["wq"]) == c["digests"]["wq"]
+    assert c["digests"]["ehs"] is None or digest(d["ehs"]) == c["digests"]["ehs"]
+    return d
+
+
 def resampler_inputs(c):
     if "x" in c:
         return c["sd"], c["x"]

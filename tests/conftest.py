@@ -47,6 +47,14 @@ def golden_geometry():
     return torch.load(os.path.join(GOLDEN, "processors_default_geometry.pt"), weights_only=False)
 
 
+@pytest.fixture(scope="session")
+def golden_legacy():
+    """Reference-source outputs of the two exported-but-unused processor classes in their garment forms: ``SAttnProcessor2_0`` (one
+    softmax over [self; garment] keys) and ``RefCAttnProcessor2_0`` (oracle/make_golden.py::main_legacy)."""
+    import torch
+    return torch.load(os.path.join(GOLDEN, "processors_legacy.pt"), weights_only=False)
+
+
 _KNOB_NAMES = ("PATCH_CONV", "SPLITK_IN_KERNEL", "FUSED_FF", "FUSED_GN_STATS", "CFG_PAIR_DEDUP", "FUSED_LN", "FUSED_OUT_PROJ", "ATTN_FP8")
 
 

@@ -790,8 +790,8 @@ def test_attention(ops, D, B, N, L1, L2, dt):
 @pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (530, 700, 0), (512, 1000, 520), (768, 1408, 1216), (512, 1344, 64)])
 @DTS
 def test_attention_d40_kernel_variants(ops, N, L1, L2, pad_one, variant, dt):
-    """The software-pipelined head-dim-40 kernel (attention_d40.hip; N >= 512) in every shipped variant -- 13: the round-4 default
-    (bf16; fp16 runs 12), 12: compile-time ring slots, 10: head-dim rows 32..40 of P.V on v_mfma_f32_16x16x32 (round-3 default),
+    """The software-pipelined head-dim-40 kernel (attention_d40.hip; N >= 512) in every shipped variant -- 13: the default
+    (interior steps unchecked; fp16 with the biased reference maximum), 12: compile-time ring slots, 10: head-dim rows 32..40 of P.V on v_mfma_f32_16x16x32 (round-3 default),
     9: the round-2 kernel, 11 / 7: the same two with register staging -- with and without the caller's K pad-column guarantee
     (LDS-DMA vs register staging), ragged key counts, a second key set on one of two batch rows, and a late spike that takes the
     exact (redo) path and raises the deferred maximum."""
@@ -799,13 +799,13 @@ def test_attention_d40_kernel_variants(ops, N, L1, L2, pad_one, variant, dt):
     assert_close(out, ref, atol=1e-2 if dt == torch.float16 else 2e-2, rtol=2e-2, what=f"attention d40 variant {variant}")
 
 
-def _run_d40_variant(ops, N, L1, L2, pad_one, variant, spike, dt):
+def _run_d40_variant(ops, N, L1, L2, pad_one, variant, spike, dt, spike_at=None):
     D, H, B = 40, 8, 2
     Cc = H * D
     dpk, dpv = ops.attn_padded_dims(D)
     q = rnd(1, B, N, Cc).to(dt)
     k1 = rnd(2, B, L1, Cc).to(dt); v1 = rnd(3, B, L1, Cc).to(dt)
-    k1[:, L1 - 90] = q[:, 7] * spike                     # a key far above the rest late in the sequence
+    k1[:, L1 - 90 if spike_at is None else spike_at] = q[:, 7] * spike      # a key far above the rest late in the sequence (or where the caller says)
     scale = D ** -0.5 * math.log2(math.e)
 
     def kbuf(x):
@@ -838,23 +838,29 @@ def _run_d40_variant(ops, N, L1, L2, pad_one, variant, spike, dt):
 
 
 @pytest.mark.parametrize("N,L1,L2", [(640, 640, 330), (512, 1000, 520), (768, 1408, 0)])
-def test_attention_d40_unchecked_steps_rerun_on_overflow(ops, N, L1, L2):
-    """Variant 13 (bf16 default) tests the deferred maximum only on the first and last steps of a phase.  A key whose score sits 170..400
-    (base-2 units) above everything the first block held makes P = 2^(s - m_ref) overflow fp32 for query 7 of every head: the
-    workgroups of query rows 0..255 find an infinite softmax denominator and run again as variant 12 -- their output must be variant
-    12's bit for bit (and finite: without the re-run those rows are NaN).  Workgroups whose scores stay below 2^127 keep the
-    unchecked result, which differs from 12's by rounding only (12 rescales where 13 lets P grow)."""
-    dt = torch.bfloat16
+@pytest.mark.parametrize("where", ["late", "interior"])
+@DTS
+def test_attention_d40_unchecked_steps_rerun_on_overflow(ops, N, L1, L2, where, dt):
+    """Variant 13 (the default of both element types) tests the deferred maximum only on the first and last steps of a phase.  A key whose
+    score sits far above everything the first block held -- 170..400 base-2 units for bf16 (P = 2^(s - m_ref) leaves fp32), 35..80 for fp16
+    (its P = 2^(s - m_first - 4) passes 65504 at + 20) -- planted EITHER among the last keys (checked steps: the exact path raises the
+    reference maximum, nothing overflows) OR in the middle of the sequence (unchecked interior step: the workgroup of query rows 0..255
+    finds an infinite softmax denominator when the phase is done and runs again as variant 12).  Either way the rows of that workgroup
+    must be finite and -- where the re-run happened -- variant 12's bit for bit; workgroups that stay in range keep the unchecked result,
+    which differs from 12's by rounding only (12 rescales where 13 lets P grow)."""
     D, H = 40, 8
+    spike = 30.0 if dt == torch.bfloat16 else 6.0
     q = rnd(1, 2, N, H * D).to(dt).float().view(2, N, H, D)
     k0 = rnd(2, 2, L1, H * D).to(dt).float().view(2, L1, H, D)
     sc = D ** -0.5 * math.log2(math.e)
     first = torch.einsum("bhd,bkhd->bhk", q[:, 7], k0[:, :32]).amax(-1) * sc          # query 7's maximum over the first 32-key block
-    late = (q[:, 7] * q[:, 7]).sum(-1) * 30.0 * sc                                     # ... and its score on the planted key
-    assert ((late - first) > 130).all()              # 2^(s - m_ref) is past fp32's range in every head
-    out13, _ = _run_d40_variant(ops, N, L1, L2, True, 13, 30.0, dt)
-    out12, _ = _run_d40_variant(ops, N, L1, L2, True, 12, 30.0, dt)
-    assert torch.equal(out13[:, :256], out12[:, :256])
+    late = (q[:, 7] * q[:, 7]).sum(-1) * spike * sc                                    # ... and its score on the planted key
+    assert ((late - first) > (130 if dt == torch.bfloat16 else 26)).all()              # P is past the format's range in every head
+    at = None if where == "late" else (L1 // 2) // 64 * 64 + 5                         # an interior 64-key unit of the first key set
+    out13, _ = _run_d40_variant(ops, N, L1, L2, True, 13, spike, dt, spike_at=at)
+    out12, _ = _run_d40_variant(ops, N, L1, L2, True, 12, spike, dt, spike_at=at)
+    if where == "interior":
+        assert torch.equal(out13[:, :256], out12[:, :256])
     assert_close(out13, out12, atol=2e-2, rtol=2e-2, what="variant 13 vs 12 under large scores")
 
 

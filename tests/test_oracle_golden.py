@@ -6,7 +6,7 @@ import torch
 
 from oracle import processors as P
 from oracle import resampler as R
-from tests.cases import cache_inputs, cross_inputs, hybrid_inputs, proj_plus_inputs, resampler_inputs
+from tests.cases import cache_inputs, cross_inputs, hybrid_inputs, legacy_inputs, proj_plus_inputs, resampler_inputs
 
 ATOL = 2e-5
 
@@ -105,6 +105,26 @@ def test_cache_restatement_real_dims(golden_full, name):
     out = p(a, i["x"], encoder_hidden_states=i["ehs"])
     assert p.cache["hidden_states"] is i["x"]
     _close(out, c["out"])
+
+
+@pytest.mark.parametrize("name", ["sattn_d40", "sattn_d40_n640", "sattn_d160", "refc_d40", "refc_d80_self"])
+def test_legacy_garment_forms_restatement(golden_legacy, name):
+    """``SAttnProcessor2_0`` (attention_processor.py:154-159: one softmax over the concatenated keys) and ``RefCAttnProcessor2_0``
+    (:706-722) -- exported by the reference module, installed by none of its entry points."""
+    c = golden_legacy[name]
+    i = legacy_inputs(c)
+    if c["kind"] == "sattn":
+        args = (i["x"], i["wq"], i["wk"], i["wv"], i["wo"], i["bo"], c["heads"])
+        cond, plain = P.concat_self_attention(*args, ref=i["ref"]), P.concat_self_attention(*args)
+    else:
+        args = (i["x"], i["ehs"], i["wq"], i["wk"], i["wv"], i["wo"], i["bo"], c["heads"])
+        cond = P.cross_plus_garment_attention(*args, ref=i["ref"], wk_ref=i["wk_ref"], wv_ref=i["wv_ref"], scale=c["scale"])
+        plain = P.cross_plus_garment_attention(*args)
+    if c["rows"] is not None:
+        cond, plain = cond[:, c["rows"]], plain[:, c["rows"]]
+    _close(cond, c["out_garment"])
+    _close(plain, c["out_plain"])
+    assert (c["out_garment"] - c["out_plain"]).abs().max() > 1e-2
 
 
 @pytest.mark.parametrize("name", ["resampler_small", "resampler_real"])

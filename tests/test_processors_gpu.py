@@ -6,7 +6,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.cases import cache_inputs, cross_inputs, hybrid_inputs, proj_plus_inputs, resampler_inputs  # noqa: E402
+from tests.cases import cache_inputs, cross_inputs, hybrid_inputs, legacy_inputs, proj_plus_inputs, resampler_inputs  # noqa: E402
 
 DT = pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 ATOL = {torch.float16: 1e-2, torch.bfloat16: 4e-2}
@@ -306,3 +306,34 @@ def test_proj_plus_vs_reference_golden(golden_resampler, dt):
     m.load_state_dict(sd, strict=True)
     check(m(idv.cuda().to(dt), clip.cuda().to(dt)), c["out"], dt, "proj_plus")
     check(m(idv.cuda().to(dt), clip.cuda().to(dt), shortcut=True, scale=0.7), c["out_shortcut"], dt, "proj_plus shortcut")
+
+
+@DT
+@pytest.mark.parametrize("name", ["sattn_d40", "sattn_d40_n640", "sattn_d160", "refc_d40", "refc_d80_self"])
+@torch.no_grad()
+def test_legacy_garment_forms_vs_reference_golden(golden_legacy, name, dt):
+    """The two processor classes the reference module exports but no entry point installs, in their garment forms, against outputs of
+    the reference classes: ``SAttnProcessor2_0`` = ONE softmax over [self; garment] keys (attention_processor.py:154-159; one phase of
+    the fused kernel over concatenated K / V^T), ``RefCAttnProcessor2_0`` = text (or self) attention + a garment softmax through
+    to_k_ref / to_v_ref (:706-722; the hybrid kernel's two phases)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from imagdressing_amd.adapter import attention_processor as A
+    c = golden_legacy[name]
+    i = legacy_inputs(c)
+    attn = make_attn(i, c["heads"], dt)
+    pname = "blk.attn.processor"
+    if c["kind"] == "sattn":
+        proc = A.SAttnProcessor2_0(pname, c["C"])
+    else:
+        proc = A.RefCAttnProcessor2_0(pname, c["C"], c["KD"] or None, scale=c["scale"])
+        proc.to_k_ref.weight.copy_(i["wk_ref"]); proc.to_v_ref.weight.copy_(i["wv_ref"])
+    attn.set_processor(proc)
+    x = i["x"].cuda().to(dt)
+    kw = {} if i["ehs"] is None else {"encoder_hidden_states": i["ehs"].cuda().to(dt)}
+    cond = attn(x, sa_hidden_states={pname: i["ref"].cuda()}, **kw)
+    plain = attn(x, **kw)
+    if c["rows"] is not None:
+        cond, plain = cond[:, c["rows"].cuda()], plain[:, c["rows"].cuda()]
+    check(cond, c["out_garment"], dt, f"{name} garment form")
+    check(plain, c["out_plain"], dt, f"{name} plain form")

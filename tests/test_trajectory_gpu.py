@@ -1,0 +1,86 @@
+"""Full-length, full-width TRAJECTORIES of the HIP pipelines against the committed fp32-oracle latents (tests/golden/trajectory.pt;
+``python -m oracle.make_golden trajectory``): the whole path of BASELINE.json's configurations -- Resampler, garment UNet pass, every
+DDIM step of the 859.5 M-parameter UNet with the hybrid processors, custom CFG, (ControlNet, inpainting blend) -- run end to end, so
+that what only compounds over a run is pinned too: the fp32 latent state through 20 / 50 ``ddim_cfg_step`` launches, the K / V caches
+reused across all steps, the ``cfg_pair`` de-duplication, HIP-graph replay at full width, the batch-4 call of the bench workload.
+
+Bars (final latent and every kept intermediate latent; rel-rms = rms error / rms of the oracle latent, worst element in units of the
+oracle latent's sigma): fp16 1 % / 0.1 sigma; bf16 (8 mantissa bits) 6 % / 0.5 sigma.  The trajectory is a 20- / 50-fold
+composition of the UNet with guidance 7.5, so the per-forward error (fp16 0.1 %, bf16 1.2 % rms) grows along it."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.trajectory_fixture import CASES, FILE  # noqa: E402
+
+BARS = {torch.float16: dict(rel_rms=1e-2, max_sigma=0.1), torch.bfloat16: dict(rel_rms=6e-2, max_sigma=0.5)}
+
+
+def _check(ent, bar, what):
+    assert ent["rel_rms"] <= bar["rel_rms"] and ent["max_abs_over_sigma"] <= bar["max_sigma"], (what, ent, bar)
+
+
+@pytest.fixture(scope="module")
+def gold():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if not os.path.isfile(FILE):
+        pytest.fail("tests/golden/trajectory.pt is missing (python -m oracle.make_golden trajectory)")
+    return torch.load(FILE, weights_only=False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@torch.no_grad()
+def test_full_width_trajectory_vs_committed_oracle(gold, dtype):
+    """BASELINE configs[0] (20 DDIM steps, batch 1, seed 42) and configs[1] (50 steps, seeds 42 and 43): each seed alone with the
+    intermediate latents traced, then the batch-4 call (rows 0 / 1 must reproduce the seed-42 / 43 goldens; rows 2 / 3 finite) eagerly
+    and under HIP-graph replay of the step (bit-identical to the eager run)."""
+    from tests.trajectory_fixture import measure_trajectory_parity
+    for c in ("configs0_20step", "configs1_50step"):
+        assert c in gold, f"{c} missing from trajectory.pt"
+    res = measure_trajectory_parity(torch.device("cuda"), dtype, cases=("configs0_20step", "configs1_50step"))
+    bar = BARS[dtype]
+    for name in ("configs0_20step", "configs1_50step"):
+        spec = CASES[name]
+        for seed in spec["seeds"]:
+            ent = res[name][f"seed{seed}"]
+            assert ent["finite"]
+            _check(ent["final"], bar, (name, seed, "final"))
+            for k in spec["keep"]:
+                _check(ent[f"step{k}"], bar, (name, seed, k))
+    b4, b4g = res["configs1_50step"]["batch4"], res["configs1_50step"]["batch4_graph"]
+    assert b4["finite"] and b4g["bit_identical_to_eager"]
+    for k, v in b4.items():
+        if k.startswith("row"):
+            _check(v, bar, ("batch4", k))
+    import json
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/trajectory_parity.jsonl", "a") as f:
+        f.write(json.dumps(dict(dtype=str(dtype), **res)) + "\n")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("name", ["configs2_10step", "configs4_10step"])
+@torch.no_grad()
+def test_full_width_trajectory_other_configs_vs_committed_oracle(gold, name, dtype):
+    """BASELINE configs[2] (LoraRefS + LoRAIP processors, 77 + 4 tokens, pose ControlNet; 10 steps) and configs[4]'s geometry
+    (ControlNet inpainting at 768x576: latent 96x72, N = 6912, the masked blend with the re-noised image latents every step; 10 steps)."""
+    from tests.trajectory_fixture import measure_trajectory_parity
+    if name not in gold:
+        pytest.fail(f"{name} missing from trajectory.pt")
+    res = measure_trajectory_parity(torch.device("cuda"), dtype, cases=(name,), batch4=False, graph=False)
+    bar = BARS[dtype]
+    spec = CASES[name]
+    for seed in spec["seeds"]:
+        ent = res[name][f"seed{seed}"]
+        assert ent["finite"]
+        _check(ent["final"], bar, (name, seed, "final"))
+        for k in spec["keep"]:
+            _check(ent[f"step{k}"], bar, (name, seed, k))
+    import json
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/trajectory_parity.jsonl", "a") as f:
+        f.write(json.dumps(dict(dtype=str(dtype), **res)) + "\n")

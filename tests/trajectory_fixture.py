@@ -1,0 +1,220 @@
+"""Full-length, full-width TRAJECTORY fixtures (tests/golden/trajectory.pt, made by ``python -m oracle.make_golden trajectory``):
+the reference's sampling loop (IMAGDressing_v1_pipeline.py:463-541 and the ControlNet / inpainting variants) run END TO END on the
+fp32 oracle with the 859.5 M-parameter seeded UNets -- garment pass, every DDIM step, custom CFG -- and the latents after a few steps
+and after the last one committed.  This module is the seeded-input builder, the engine-side pipeline builder and the parity probe
+that bench.py (``parity.trajectory``) and tests/test_trajectory_gpu.py run against the committed file.  TEST INFRASTRUCTURE; imports
+no oracle code, so bench.py may use it outside its cpu_baseline leg.
+
+Cases (BASELINE.json ``configs``):
+  configs0_20step   fp32 oracle, 512x512, 20 DDIM steps, batch 1 (seed 42), g = 7.5                    (configs[0])
+  configs1_50step   512x512, 50 DDIM steps, seeds 42 and 43 (rows 0 / 1 of the bench batch), g = 7.5    (configs[1], the headline)
+  configs2_10step   + 4 face tokens + rank-128 LoRA + pose ControlNet, 512x512, 10 steps, g = 7.0       (configs[2])
+  configs4_10step   ControlNet inpainting at 768x576 (latent 96x72), 10 steps, g = 5.0, blend per step  (configs[4])
+"""
+import os
+
+import torch
+
+from tests.unet_fixture import GOLDEN, digest, fill_ipa_processors, ipa_controlnet_forward_inputs, unet_forward_inputs
+
+FILE = os.path.join(GOLDEN, "trajectory.pt")
+
+CASES = {
+    "configs0_20step": dict(kind="refs", lh=64, lw=64, steps=20, guidance=7.5, seeds=(42,), keep=(0, 5, 10, 19)),
+    "configs1_50step": dict(kind="refs", lh=64, lw=64, steps=50, guidance=7.5, seeds=(42, 43), keep=(0, 10, 25, 49)),
+    "configs2_10step": dict(kind="ipa_controlnet", lh=64, lw=64, steps=10, guidance=7.0, seeds=(42,), keep=(0, 5, 9),
+                            conditioning_scale=1.0),
+    "configs4_10step": dict(kind="inpaint", lh=96, lw=72, steps=10, guidance=5.0, seeds=(42,), keep=(0, 5, 9),
+                            conditioning_scale=1.0),
+}
+
+RESAMPLER_CFG = dict(dim=768, depth=4, dim_head=64, heads=12, num_queries=16, embedding_dim=1280, output_dim=768, ff_mult=4)
+
+
+def rnd(seed, *shape, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def resampler_state_dict(seed=3):
+    """State dict of the garment Resampler (inference_IMAGdressing.py:55-64) drawn by torch's own nn.Linear / LayerNorm initialisers
+    from a forked, seeded CPU generator (identical on every host) -- the engine class is only a parameter container here."""
+    from imagdressing_amd.adapter.resampler import Resampler
+    with torch.random.fork_rng(devices=[]):
+        torch.manual_seed(seed)
+        m = Resampler(**RESAMPLER_CFG)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def trajectory_inputs(kind, lh, lw, base=None):
+    """CPU tensors of one trajectory family: the denoising UNet (seed 0; shared with unet_forward_inputs), the garment UNet (seed 1),
+    to_k_ref / to_v_ref (seed 7), the Resampler (seed 3), prompt / negative text states, garment CLIP states [1, 257, 1280] and garment
+    latent, plus per kind the configs[2] additions (tests/unet_fixture.py::ipa_controlnet_forward_inputs) or the inpainting ones
+    (ControlNet seed 2, image latents, 40 % centred mask, control image)."""
+    from imagdressing_amd import unet as E
+    d = dict(base) if base is not None else unet_forward_inputs(lh, lw)
+    if kind == "ipa_controlnet" and "ctrl_sd" not in d:
+        d = ipa_controlnet_forward_inputs(base=d)
+    d["sd_ref"] = E.random_state_dict(E.unet_param_shapes(E.SD15_CONFIG), 1)
+    d["resampler_sd"] = resampler_state_dict(3)
+    d["pe"] = d["ehs"]                                             # rnd(2, 1, 77, 768) * 0.5
+    d["ne"] = rnd(3, 1, 77, 768, scale=0.5)
+    d["clip"] = rnd(20, 1, 257, 1280, scale=0.5)
+    d["refl"] = rnd(13, 1, 4, lh, lw)
+    if kind == "inpaint":
+        d["ctrl_sd"] = E.random_state_dict(E.controlnet_param_shapes(E.SD15_CONFIG), 2, zero_convs=True)
+        d["img_lat"] = rnd(17, 1, 4, lh, lw)
+        m = torch.zeros(1, 1, lh, lw)
+        m[:, :, int(lh * 0.184): int(lh * 0.816), int(lw * 0.184): int(lw * 0.816)] = 1.0
+        d["mask"] = m
+        d["control_image"] = torch.rand(1, 3, 8 * lh, 8 * lw, generator=torch.Generator().manual_seed(18))
+    d["traj_digests"] = dict(sd_ref=digest(d["sd_ref"]["conv_in.weight"]), resampler=digest(d["resampler_sd"]["latents"]),
+                             ne=digest(d["ne"]), clip=digest(d["clip"]), refl=digest(d["refl"]), sd=d["digests"]["sd"])
+    return d
+
+
+def initial_latents(seeds, lh, lw):
+    return torch.stack([torch.randn(4, lh, lw, generator=torch.Generator().manual_seed(s)) for s in seeds])
+
+
+def build_engine_pipeline(kind, d, device, dtype):
+    """The HIP pipeline of one trajectory family on ``device`` from the CPU tensors of :func:`trajectory_inputs`."""
+    from imagdressing_amd import unet as E
+    from imagdressing_amd.adapter import attention_processor as AP
+    from imagdressing_amd.adapter.resampler import Resampler
+    from imagdressing_amd.scheduler import DDIMScheduler
+    from tests.harness_names import hidden_size_of
+    boc = E.SD15_CONFIG["block_out_channels"]
+    unet = E.UNet2DConditionModel(d["sd"], {}, str(device), dtype)
+    ref = E.UNet2DConditionModel(d["sd_ref"], {}, str(device), dtype)
+    if kind == "ipa_controlnet":
+        procs = {n: (AP.LoraRefSAttnProcessor2_0(n, hidden_size_of(n, boc), scale=d["ref_scale"], rank=d["rank"], lora_scale=d["lora_scale"])
+                     if n.endswith("attn1.processor") else
+                     AP.LoRAIPAttnProcessor2_0(hidden_size_of(n, boc), 768, rank=d["rank"], lora_scale=d["lora_scale"], scale=d["ip_scale"], num_tokens=4))
+                 for n in unet.attn_processors.keys()}
+        fill_ipa_processors(procs, d)
+    else:
+        procs = {n: (AP.RefSAttnProcessor2_0(n, hidden_size_of(n, boc)) if n.endswith("attn1.processor")
+                     else AP.CAttnProcessor2_0(n, hidden_size_of(n, boc), 768)) for n in unet.attn_processors.keys()}
+        with torch.no_grad():
+            for n in d["names"]:
+                procs[n].to_k_ref.weight.copy_(d["rw"][n]["k"]); procs[n].to_v_ref.weight.copy_(d["rw"][n]["v"])
+    unet.set_attn_processor(procs)
+    ref.set_attn_processor({n: AP.CacheAttnProcessor2_0() for n in ref.attn_processors.keys()})
+    proj = Resampler(**RESAMPLER_CFG)
+    proj.load_state_dict(d["resampler_sd"], strict=True)
+    sch = DDIMScheduler(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                        clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+    common = dict(vae=None, reference_unet=ref, unet=unet, tokenizer=None, text_encoder=None, image_encoder=None, ImgProj=proj, scheduler=sch)
+    if kind == "refs":
+        from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
+        return IMAGDressing_v1(**common)
+    ctrl = E.ControlNetModel(d["ctrl_sd"], {}, str(device), dtype)
+    if kind == "ipa_controlnet":
+        from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline_ipa_controlnet import IMAGDressing_v1
+        pipe = IMAGDressing_v1(controlnet=ctrl, ip_ckpt=None, **common)
+        face_p, face_n = d["ehs_c"][:, 77:], d["ehs_u"][:, 77:]
+
+        class FaceProj:        # image_proj_model stand-in returning the fixture's face tokens (ProjPlusModel has its own pinned golden)
+            def __call__(self, idv, clip):
+                return (face_p if float(idv.abs().sum()) > 0 else face_n).to(device)
+        pipe.image_proj_model = FaceProj()
+        return pipe
+    from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline_controlnet_inpainting import IMAGDressing_v1
+    return IMAGDressing_v1(controlnet=ctrl, **common)
+
+
+def call_kwargs(kind, spec, d, lat, device, dtype):
+    lh, lw = spec["lh"], spec["lw"]
+    kw = dict(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=8 * lw, height=8 * lh,
+              num_inference_steps=spec["steps"], guidance_scale=spec["guidance"], num_images_per_prompt=lat.shape[0],
+              prompt_embeds=d["pe"].to(device), negative_prompt_embeds=d["ne"].to(device),
+              ref_clip_hidden_states=d["clip"].to(device=device, dtype=dtype), ref_image_latents=d["refl"].to(device),
+              output_type="latent")
+    if kind == "refs":
+        kw.update(image_scale=1.0, latents=lat.to(device))
+    elif kind == "ipa_controlnet":
+        kw.update(pose_image=d["pose"].to(device), faceid_embeds=torch.ones(1, 512), face_clip_hidden_states=torch.zeros(1, 257, 1280),
+                  face_uncond_clip_hidden_states=torch.zeros(1, 257, 1280), image_scale=d["ref_scale"], ipa_scale=d["ip_scale"],
+                  s_lora_scale=d["lora_scale"], c_lora_scale=d["lora_scale"], controlnet_conditioning_scale=spec["conditioning_scale"],
+                  latents=lat.to(device))
+    else:
+        kw.update(control_image=d["control_image"].to(device), image_latents=d["img_lat"].to(device), mask_latents=d["mask"].to(device),
+                  noise=lat.to(device), controlnet_conditioning_scale=spec["conditioning_scale"], image_scale=1.0)
+    return kw
+
+
+def _stats(got, ref):
+    """Error of a latent against the oracle's, relative to the oracle latent's own scale (sigma of its elements)."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    err = (got - ref).abs()
+    sigma = ref.std().item()
+    return dict(rel_rms=round((err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item(), 5), max_abs=round(err.max().item(), 5),
+                max_abs_over_sigma=round(err.max().item() / sigma, 5), sigma=round(sigma, 4),
+                frac_within_1e2=round((err <= 1e-2).float().mean().item(), 5))
+
+
+@torch.no_grad()
+def run_engine_trajectory(pipe, kind, spec, d, seeds, device, dtype, trace=True, graph=False):
+    """-> (final latents [B, 4, lh, lw] fp32 on the CPU, {step: latents} for every traced step or {})"""
+    lat = initial_latents(seeds, spec["lh"], spec["lw"])
+    kw = call_kwargs(kind, spec, d, lat, device, dtype)
+    tr = [] if trace else None
+    pipe.enable_step_graph(graph)
+    try:
+        out = pipe(trace=tr, **kw).images.float().cpu()
+    finally:
+        pipe.enable_step_graph(False)
+    B = lat.shape[0]
+    steps = {}
+    if tr:
+        for i, z in enumerate(tr):
+            steps[i] = z.view(B, spec["lh"], spec["lw"], 4).permute(0, 3, 1, 2).float().cpu()
+    return out, steps
+
+
+@torch.no_grad()
+def measure_trajectory_parity(device, dtype, cases=("configs0_20step", "configs1_50step"), base=None, batch4=True, graph=True):
+    """Run the HIP pipelines over the committed trajectories.  Per case and seed: error of the latent after each kept step and of the
+    FINAL latent (rel-rms; worst element in units of the oracle latent's sigma).  For configs1_50step additionally (``batch4``) the
+    batch-4 call of the bench workload -- row i must reproduce the seed-(42+i) golden -- and (``graph``) the HIP-graph replay of the
+    step.  -> {case: {"seed42": {"final": {...}, "step10": {...}}, ..., "worst_final_rel_rms": x}}"""
+    from imagdressing_amd import ops
+    gold = torch.load(FILE, weights_only=False)
+    res, pipes = {}, {}
+    shared = base
+    for name in cases:
+        spec, g = CASES[name], gold[name]
+        kind = spec["kind"]
+        key = (kind, spec["lh"], spec["lw"])
+        if key not in pipes:
+            pipes.clear(); ops.clear_workspaces(); torch.cuda.empty_cache()
+            d = trajectory_inputs(kind, spec["lh"], spec["lw"], base=shared if (spec["lh"], spec["lw"]) == (64, 64) else None)
+            if (spec["lh"], spec["lw"]) == (64, 64) and shared is None:
+                shared = {k: d[k] for k in ("sd", "x", "ehs", "rw", "sa", "names", "digests")}
+            pipes[key] = (build_engine_pipeline(kind, d, device, dtype), d)
+        pipe, d = pipes[key]
+        assert d["traj_digests"] == g["digests"], ("regenerated trajectory inputs differ from the fixture's", d["traj_digests"], g["digests"])
+        out = {}
+        finals = []
+        for si, seed in enumerate(spec["seeds"]):
+            fin, steps = run_engine_trajectory(pipe, kind, spec, d, (seed,), device, dtype, trace=True)
+            ent = {"final": _stats(fin, g["final"][si:si + 1]), "finite": bool(torch.isfinite(fin).all())}
+            for k in spec["keep"]:
+                ent[f"step{k}"] = _stats(steps[k], g["steps"][k][si:si + 1])
+            out[f"seed{seed}"] = ent
+            finals.append(ent["final"]["rel_rms"])
+        if name == "configs1_50step" and batch4:
+            seeds4 = tuple(spec["seeds"]) + tuple(max(spec["seeds"]) + 1 + i for i in range(4 - len(spec["seeds"])))
+            fin, _ = run_engine_trajectory(pipe, kind, spec, d, seeds4, device, dtype, trace=False)
+            out["batch4"] = {f"row{i}_vs_seed{s}": _stats(fin[i:i + 1], g["final"][i:i + 1]) for i, s in enumerate(spec["seeds"])}
+            out["batch4"]["finite"] = bool(torch.isfinite(fin).all())
+            finals += [v["rel_rms"] for k, v in out["batch4"].items() if k.startswith("row")]
+            if graph:
+                fing, _ = run_engine_trajectory(pipe, kind, spec, d, seeds4, device, dtype, trace=False, graph=True)
+                out["batch4_graph"] = {f"row{i}_vs_seed{s}": _stats(fing[i:i + 1], g["final"][i:i + 1]) for i, s in enumerate(spec["seeds"])}
+                out["batch4_graph"]["bit_identical_to_eager"] = bool(torch.equal(fin, fing))
+                finals += [v["rel_rms"] for k, v in out["batch4_graph"].items() if k.startswith("row")]
+        out["worst_final_rel_rms"] = max(finals)
+        res[name] = out
+    pipes.clear(); ops.clear_workspaces(); torch.cuda.empty_cache()
+    return res
