@@ -467,7 +467,12 @@ int g_attn_xcd = 1;
 
 int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
-    p.flags = g_attn_xcd ? 0 : 1;
+    // tuning of this call: the caller's (IMD_TUNING_PER_CALL in flags on entry: bits 0..7 head-dim-40 variant, bit 8 plain work order) or the
+    // process-wide knobs 0 / 1
+    const bool per_call = (p_in.flags & IMD_TUNING_PER_CALL) != 0;
+    const int qw40 = (per_call && (p_in.flags & 255)) ? (p_in.flags & 255) : g_attn_qw40;
+    if (qw40 < 1 || qw40 > 54) return imd_set_error("attention: per-call head-dim-40 variant %d out of range", qw40);
+    p.flags = (per_call ? !((p_in.flags >> 8) & 1) : g_attn_xcd != 0) ? 0 : 1;
     if (p.B <= 0 || p.H <= 0 || p.N <= 0 || p.L1 <= 0) return imd_set_error("attention: empty problem B=%d H=%d N=%d L1=%d", p.B, p.H, p.N, p.L1);
     if (p.L1P % 64 || p.L1P < p.L1) return imd_set_error("attention: L1P (%d) must be a multiple of 64 and >= L1 (%d)", p.L1P, p.L1);
     if (p.k2 && (p.L2 <= 0 || p.L2P % 64 || p.L2P < p.L2)) return imd_set_error("attention: bad second key set L2=%d L2P=%d", p.L2, p.L2P);
@@ -490,12 +495,12 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     }
     switch (p.D) {
         case 40:
-            if (g_attn_qw40 >= 6 && p.N >= 512 && !p.causal) return imd_launch_attention_d40(p, g_attn_qw40, s);
-            if (g_attn_qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 1>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 1>(p, s);
-            if (g_attn_qw40 == 5 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 3>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 3>(p, s);
-            if (g_attn_qw40 == 3) return h ? launch_attn<true, 40, 1, 3, 2, false>(p, s) : launch_attn<false, 40, 1, 3, 2, false>(p, s);
-            if (g_attn_qw40 == 4) return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
-            if (g_attn_qw40 == 1 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 0>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 0>(p, s);
+            if (qw40 >= 6 && p.N >= 512 && !p.causal) return imd_launch_attention_d40(p, qw40, s);
+            if (qw40 == 2 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 1>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 1>(p, s);
+            if (qw40 == 5 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 3>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 3>(p, s);
+            if (qw40 == 3) return h ? launch_attn<true, 40, 1, 3, 2, false>(p, s) : launch_attn<false, 40, 1, 3, 2, false>(p, s);
+            if (qw40 == 4) return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
+            if (qw40 == 1 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 0>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 0>(p, s);
             return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
         case 64: return h ? launch_attn<true, 64, 1, 2>(p, s) : launch_attn<false, 64, 1, 2>(p, s);
         case 80: return h ? launch_attn<true, 80, 1, 2>(p, s) : launch_attn<false, 80, 1, 2>(p, s);

@@ -130,14 +130,22 @@ int imd_groupnorm_coeffs(const imd_groupnorm_params* p, float* coef_a, float* co
 }
 
 static bool sized(const imd_conv_gemm_params* p) { return p && p->struct_bytes == sizeof(*p); }      // (queries answer 0 for a foreign layout)
-int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch_supported(*p)) ? 1 : 0; }
-int imd_conv_patch2_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch2_supported(*p)) ? 1 : 0; }
-int imd_conv_patch3_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch3_supported(*p)) ? 1 : 0; }
-int imd_conv_patch4_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_patch4_supported(*p)) ? 1 : 0; }
-int imd_conv_img_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_img_supported(*p)) ? 1 : 0; }
+// the queries see the block as the launcher will: with the operand extents filled in (a caller's block still has them at zero, which would
+// let the "< 2 GiB" clauses of the LDS-DMA kernels pass for any size); an operand beyond 4 GiB is "not supported"
+static int query(const imd_conv_gemm_params* p, bool (*pred)(const imd_conv_gemm_params&)) {
+    if (!sized(p)) return 0;
+    imd_conv_gemm_params q = *p;
+    if (!imd_conv_gemm_fill_extents(q)) return 0;
+    return pred(q) ? 1 : 0;
+}
+int imd_conv_patch_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_conv_patch_supported)); }
+int imd_conv_patch2_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_conv_patch2_supported)); }
+int imd_conv_patch3_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_conv_patch3_supported)); }
+int imd_conv_patch4_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_conv_patch4_supported)); }
+int imd_conv_img_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_conv_img_supported)); }
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return sized(p) ? imd_conv_patch_stats_parts_of(*p) : 0; }
 int imd_conv_gemm_stats_parts(const imd_conv_gemm_params* p, int cfg) { return sized(p) ? imd_conv_gemm_stats_parts_of(*p, cfg) : 0; }
-int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_gemm_dma_supported(*p)) ? 1 : 0; }
+int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_gemm_dma_supported)); }
 
 int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (sized(p) && (imd_row_linear_supported(*p) || imd_row_linear_k640_supported(*p) || imd_row_linear_k1280_supported(*p) || imd_row_qkv_supported(*p))) ? 1 : 0; }
 

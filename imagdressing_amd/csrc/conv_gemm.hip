@@ -453,11 +453,11 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 4: case 5: case 8: case 29: *bm = 128; *bn = 128; return 0;
         case 3: case 7: *bm = 64; *bn = 64; return 0;
         case 6: *bm = 64; *bn = 320; return 0;
-        case 9: case 21: *bm = 256; *bn = 128; return 0;
+        case 9: case 21: case 30: case 31: *bm = 256; *bn = 128; return 0;
         case 22: *bm = 128; *bn = 160; return 0;
         case 23: *bm = 256; *bn = 160; return 0;
         case 24: *bm = 512; *bn = 64; return 0;
-        case 10: case 16: *bm = 256; *bn = 256; return 0;
+        case 10: case 16: case 32: *bm = 256; *bn = 256; return 0;
         case 17: case 18: case 19: case 20: case 25: case 26: case 27: case 28: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
         default: return 1;
@@ -485,7 +485,7 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28) || (cfg >= 30 && cfg <= 32)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
@@ -515,6 +515,19 @@ int imd_conv_gemm_choose_split(int M, int N, int K, int cfg) {
     return s < 1 ? 1 : (int)s;
 }
 
+// buffer-descriptor extents of the two operands (x_bytes / w_bytes: "filled in by the library"); false when one exceeds 4 GiB.  Shared by the
+// launcher and by the *_supported queries of the C ABI, whose callers hand in blocks with these fields still zero.
+bool imd_conv_gemm_fill_extents(ConvGemmParams& p) {
+    if (p.Hout <= 0 || p.Wout <= 0 || p.M <= 0) return false;
+    const size_t npix = (size_t)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win;
+    if (npix == 0) return false;
+    const size_t xb = ((npix - 1) * (size_t)p.x_pix_stride + p.Cin) * 2, wb = (size_t)p.N * p.K * 2;
+    if (xb >= 0xffffffffull || wb >= 0xffffffffull) return false;
+    p.x_bytes = (uint32_t)xb;
+    p.w_bytes = (uint32_t)wb;
+    return true;
+}
+
 int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     ConvGemmParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return imd_set_error("conv_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -525,33 +538,32 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     if (p.K != p.taps * p.Cin) return imd_set_error("conv_gemm: K (%d) != taps*Cin (%d)", p.K, p.taps * p.Cin);
     if (p.mode == OUT_HEADS && (p.hD % 8)) return imd_set_error("conv_gemm: head dim (%d) must be a multiple of 8", p.hD);
     if (p.act == ACT_GEGLU && (p.N % 8)) return imd_set_error("conv_gemm: GEGLU needs N %% 8 == 0");
-    const size_t npix = (size_t)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win;
-    const size_t xb = ((npix - 1) * (size_t)p.x_pix_stride + p.Cin) * 2, wb = (size_t)p.N * p.K * 2;
-    if (xb >= 0xffffffffull || wb >= 0xffffffffull) return imd_set_error("conv_gemm: operand larger than 4 GiB");
-    p.x_bytes = (uint32_t)xb;
-    p.w_bytes = (uint32_t)wb;
+    if (!imd_conv_gemm_fill_extents(p)) return imd_set_error("conv_gemm: operand larger than 4 GiB");
     if (cfg < 0) cfg = imd_conv_gemm_choose_cfg(p.M, p.N);
     if (p.split_k < 1) p.split_k = 1;
+    // tuning bits of this call: the caller's (IMD_TUNING_PER_CALL in flags on entry) or the process-wide knob 2
+    const int gf = (p_in.flags & IMD_TUNING_PER_CALL) ? ((p_in.flags & 31) | (g_gemm_flags & ~31)) : g_gemm_flags;
     {
         const int bk = (cfg == 4) ? 32 : 64;
         p.flags = 0;
         // measured (profiles/r1g_gemm_flags_ab.jsonl): +8..17 % on the 64x64 / 32x32 feature maps, -2..4 % on 16x16 / 8x8
         const bool big_map = p.taps == 9 && p.Wout >= 32;
-        if ((g_gemm_flags & 1) && big_map && (p.Cin % bk) == 0) p.flags |= 1;
-        if ((g_gemm_flags & 2) && big_map) p.flags |= 2;
+        if ((gf & 1) && big_map && (p.Cin % bk) == 0) p.flags |= 1;
+        if ((gf & 2) && big_map) p.flags |= 2;
     }
-    if (g_gemm_flags & 4) {
+    if (gf & 4) {
         int bm = 128, bn = 128;
         tile_dims(cfg, &bm, &bn);
         p.flags |= imd_gemm_pick_order(p, (p.N + bn - 1) / bn);
-        p.flags |= g_gemm_flags & 16;
+        p.flags |= gf & 16;
     }
     if (p.split_k <= 1) p.splitk_counters = nullptr;
-    // GroupNorm statistics of the output (ABI v6+): only the halo-patch kernel's un-split epilogue produces them; every other request is an
+    // GroupNorm statistics of the output (ABI v6+): the halo-patch kernels' un-split epilogues (tile configs 5 / 22 / 23 / 29) and the finish
+    // launch of any K-sliced problem produce them (imd_conv_gemm_stats_parts_of); every other request is an
     // ERROR -- a launch that silently skipped the write would leave the next imd_groupnorm(nparts > 0) reading uninitialised memory, and
     // gn_stats_groups = 0 / fewer than 8 channels per group would divide by zero / straddle more than two groups in the kernel
     if (p.gn_stats_out != nullptr && imd_conv_gemm_stats_parts_of(p, cfg) == 0)
-        return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 without K slices or any K-sliced launch with a separate finish, a row-major 16-bit "
+        return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 / 22 / 23 / 29 without K slices or any K-sliced launch with a separate finish, a row-major 16-bit "
                              "output and 1 <= groups <= 64 with N %% groups == 0 and N / groups >= 8 (got cfg=%d split_k=%d groups=%d N=%d); ask "
                              "imd_conv_gemm_stats_parts() first", cfg, p.split_k, p.gn_stats_groups, p.N);
     if (p.splitk_counters != nullptr) {          // one counter per output tile; larger grids keep the two-launch path
@@ -617,6 +629,13 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             int rc = imd_launch_conv_img(p, s);
             if (rc) return rc;
             return launch_splitk_finish(p, s, "conv_img split-K finish");
+        }
+        case 30: case 31: case 32: {   // 256-row LDS-DMA tiles, register epilogue (gemm_dma256.hip): 30 = 256 x 128 x 64, three stages, persistent over
+                                       // (tile, K slice) items; 31 = the same with one item per workgroup; 32 = 256 x 256 x 64, two stages, persistent
+            p.splitk_counters = nullptr;
+            int rc = imd_launch_gemm_dma256(p, cfg - 30, s);
+            if (rc || p.split_k <= 1) return rc;
+            return launch_splitk_finish(p, s, "gemm_dma256 split-K finish");
         }
         case 12: return imd_launch_row_linear(p, 0, 0.f, s);      // row-resident kernel (row_linear.hip): K = 320, N <= 320
         case 13: return imd_launch_row_linear_k640(p, 0, 0.f, s); // row-resident split-K kernel (row_linear_k640.hip): K = 640, N % 160 == 0

@@ -49,6 +49,8 @@ template <int NW> struct T3 {
 __device__ constexpr unsigned char kColPix3[32] = {0, 1, 2, 3, 8, 9, 10, 11, 12, 13, 14, 15, 4, 5, 6, 7,
                                                    30, 31, 16, 17, 22, 23, 24, 25, 26, 27, 28, 29, 18, 19, 20, 21};
 
+// (launch bound 2 also for NW = 8, which runs one workgroup per CU: under the resulting 128-register cap hipcc fits the eight-wave body in 100 VGPRs
+// with NO scratch (-Rpass-analysis=kernel-resource-usage); with the cap lifted it takes 198 for the same loop -- the shipped, measured code is kept)
 template <bool F16, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void conv3x3_patch3_kernel(const ConvGemmParams p) {
     using E = El<F16>;

@@ -24,6 +24,7 @@ int imd_check_launch(const char* what);
 int imd_conv_gemm_choose_cfg(int M, int N);
 int imd_conv_gemm_choose_split(int M, int N, int K, int cfg);
 int imd_launch_conv_gemm(const ConvGemmParams& p, int cfg, hipStream_t s);
+bool imd_conv_gemm_fill_extents(ConvGemmParams& p);          // x_bytes / w_bytes from the geometry (false: an operand exceeds 4 GiB)
 bool imd_conv_patch_supported(const ConvGemmParams& p);
 bool imd_conv_patch2_supported(const ConvGemmParams& p);      // conv_patch2.hip: 16 x 16 pixel tiles (tile config 21)
 int imd_launch_conv_patch2(const ConvGemmParams& p, hipStream_t s);
@@ -50,6 +51,7 @@ int imd_launch_row_qkv(const ConvGemmParams& p, int ln, float ln_eps, hipStream_
 bool imd_gemm_dma_supported(const ConvGemmParams& p);                                       // gemm_dma.hip
 int imd_launch_gemm_dma(const ConvGemmParams& p, hipStream_t s);
 int imd_launch_gemm_dma128(const ConvGemmParams& p, int stages, hipStream_t s);      // stages: 3 | 4 ring stages
+int imd_launch_gemm_dma256(const ConvGemmParams& p, int form, hipStream_t s);        // gemm_dma256.hip: 0 = 256x128 persistent, 1 = 256x128, 2 = 256x256 persistent (tile configs 30 / 31 / 32)
 bool imd_conv_dma_supported(const ConvGemmParams& p);                         // gemm_dma.hip: 128 x 128 x 32, 3-stage ring (tile config 17)
 int imd_launch_ff_geglu(const imd_ff_params& p, hipStream_t s);                              // ff_fused.hip
 int imd_launch_attention(const AttnParams& p, hipStream_t s);
