@@ -200,6 +200,55 @@ def cpu_baseline(args):
                        f"extrapolated x{args.ddim_steps}{note}")
 
 
+def kernel_level_baseline(device, dtype, cores):
+    """BASELINE.md section 4.1 / SURVEY 8(d) CPU-baseline plan (i): the hybrid processor ALONE -- ``RefSAttnProcessor2_0`` semantics
+    (oracle/processors.py::hybrid_self_attention, pinned on the reference source; fp32 torch on `cores` threads, 2 warm-up + 5 timed calls)
+    beside the HIP processor (three launches: q/k/v projection, fused two-softmax attention, out-projection + bias; HIP events over 20
+    calls after 3 warm-up, garment K / V cached as in the loop) at the four (C, N = M) shapes of the 512x512 UNet, batch 1, garment
+    branch on.  FLOPs per call: 8 N C^2 + 4 N^2 C + 4 N M C (the garment K / V projection is once per garment: excluded on both sides)."""
+    from imagdressing_amd.adapter import attention_processor as AP
+    from imagdressing_amd.unet import Attention
+    from oracle import processors as OP
+    torch.set_num_threads(cores)
+    rows = []
+    g = torch.Generator().manual_seed(77)
+    for C, N in ((320, 4096), (640, 1024), (1280, 256), (1280, 64)):
+        M = N
+        w = {k: torch.randn(C, C, generator=g) * C ** -0.5 for k in ("wq", "wk", "wv", "wo", "wkr", "wvr")}
+        bo = torch.randn(C, generator=g) * 0.1
+        x, ref = torch.randn(1, N, C, generator=g), torch.randn(1, M, C, generator=g)
+        fl = 8.0 * N * C * C + 4.0 * N * N * C + 4.0 * N * M * C
+        with torch.no_grad():
+            def cpu_call():
+                return OP.hybrid_self_attention(x, w["wq"], w["wk"], w["wv"], w["wo"], bo, 8, ref=ref, wk_ref=w["wkr"], wv_ref=w["wvr"], scale=1.0)
+            for _ in range(2):
+                cpu_call()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                cpu_out = cpu_call()
+            cpu_ms = (time.perf_counter() - t0) / 5 * 1e3
+            sd = {"a.to_q.weight": w["wq"], "a.to_k.weight": w["wk"], "a.to_v.weight": w["wv"], "a.to_out.0.weight": w["wo"], "a.to_out.0.bias": bo}
+            attn = Attention(sd, "a", 8, str(device), dtype)
+            proc = AP.RefSAttnProcessor2_0("blk.attn1.processor", C)
+            proc.to_k_ref.weight.copy_(w["wkr"]); proc.to_v_ref.weight.copy_(w["wvr"])
+            attn.set_processor(proc)
+            xd, sa = x.to(device=device, dtype=dtype), {"blk.attn1.processor": ref.to(device)}
+            for _ in range(3):
+                out = attn(xd, sa_hidden_states=sa)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                out = attn(xd, sa_hidden_states=sa)
+            e1.record(); torch.cuda.synchronize()
+            hip_us = e0.elapsed_time(e1) / 20 * 1e3
+            err = (out.float().cpu() - cpu_out).abs().max().item()
+        rows.append({"C": C, "N": N, "M": M, "gflop": round(fl / 1e9, 3), "cpu_ms": round(cpu_ms, 3), "cpu_gflops": round(fl / cpu_ms / 1e6, 1),
+                     "hip_us": round(hip_us, 2), "hip_tflops": round(fl / hip_us / 1e6, 1), "speedup": round(cpu_ms * 1e3 / hip_us, 1),
+                     "max_abs_diff_hip_vs_cpu": round(err, 5)})
+    return {"what": "hybrid attention processor alone (RefSAttnProcessor2_0, garment branch on, batch 1): fp32 CPU port of the reference processor vs "
+                    f"the HIP processor ({str(dtype).replace('torch.', '')}), per UNet level of the 512x512 geometry", "cores": cores, "shapes": rows}
+
+
 def run_other_config(cid, what, device, dtype, args, runs=3):
     """Timed runs of another single-GPU BASELINE configuration (tools/configs.py builds pipeline + synthetic inputs resident in HBM):
     one warm-up run, then `runs` timed runs of the whole call -- garment pass, ControlNet + UNet loop, VAE decode of the images."""
@@ -497,7 +546,27 @@ def main():
                                   finite=all(v["finite"] for c in r.values() for k, v in c.items() if k.startswith("t")))
                 parity[nm]["meets_atol_1e-2"] = bool(parity[nm]["max_abs"] <= 1e-2)
             parity["meets_atol_1e-2"] = [nm for nm in ("fp16", "bf16") if parity[nm]["meets_atol_1e-2"]]
-            del base_inputs, ipa_inputs
+            del ipa_inputs
+            # full-LENGTH trajectories against the committed fp32-oracle latents (tests/golden/trajectory.pt): the whole pipeline call --
+            # Resampler, garment pass, 20 / 50 DDIM steps, CFG -- for BASELINE configs[0] (20 steps, seed 42) and configs[1] (50 steps,
+            # seeds 42 / 43; then the batch-4 call and its HIP-graph replay, rows 0 / 1 against the same goldens)
+            try:
+                from tests import trajectory_fixture as TF
+                traj = {"what": "final latent (and latents after a few steps) of the whole pipeline call against oracle/pipeline.py::denoise on the fp32 oracle "
+                                "(tests/golden/trajectory.pt); rel_rms = rms error / rms of the oracle latent, max_abs_over_sigma = worst element / sigma of the "
+                                "oracle latent; the trajectory composes the UNet 20 / 50 times at guidance 7.5, so per-forward error grows along it"}
+                for nm, d_ in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+                    r = TF.measure_trajectory_parity(device, d_, cases=("configs0_20step", "configs1_50step"), base=base_inputs)
+                    traj[nm] = {"configs0_20step_final": r["configs0_20step"]["seed42"]["final"],
+                                "configs1_50step_final": {k: v["final"] for k, v in r["configs1_50step"].items() if k.startswith("seed")},
+                                "configs1_50step_batch4": r["configs1_50step"].get("batch4"), "configs1_50step_batch4_graph": r["configs1_50step"].get("batch4_graph"),
+                                "worst_final_rel_rms": max(r["configs0_20step"]["worst_final_rel_rms"], r["configs1_50step"]["worst_final_rel_rms"]),
+                                "detail": r}
+                TF.clear_input_cache()
+                parity["trajectory"] = traj
+            except Exception as e:       # noqa: BLE001
+                parity["trajectory"] = {"error": f"{type(e).__name__}: {e}"}
+            del base_inputs
             ops.clear_workspaces(); torch.cuda.empty_cache()
         except Exception as e:       # noqa: BLE001
             parity = {"error": f"{type(e).__name__}: {e}"}
@@ -610,6 +679,10 @@ def main():
             line["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
+            try:
+                line["cpu_baseline"]["kernel_level"] = kernel_level_baseline(device, dtype, line["cpu_baseline"]["cores"])
+            except Exception as e:       # noqa: BLE001
+                line["cpu_baseline"]["kernel_level"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

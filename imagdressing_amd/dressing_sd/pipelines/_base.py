@@ -93,6 +93,14 @@ class PipelineBase:
 
     _execution_device = device
 
+    def set_tuning(self, attn_variant: Optional[int] = None, attn_xcd: Optional[bool] = None, gemm_flags: Optional[int] = None):
+        """Kernel tuning of THIS pipeline's launches (head-dim-40 attention variant, XCD-aware attention work order, GEMM tuning bits 0..4),
+        carried per call in the params blocks (``ops.tuning_scope``, ``IMD_TUNING_PER_CALL``): two pipelines of one process may differ and
+        the library's process-wide knobs (``imd_set_tuning``) are not touched.  All None (the default) = the process-wide settings."""
+        self._tuning = dict(attn_variant=attn_variant, attn_xcd=attn_xcd, gemm_flags=gemm_flags)
+        self.release_step_graph()            # a captured step graph bakes its kernels in
+        return self
+
     def enable_step_graph(self, flag: bool = True):
         """Opt in to HIP-graph replay of the DDIM denoising step (see ``denoise``): same kernels, same arithmetic, one graph launch
         per step instead of ~500 kernel launches.  Worth it where the loop is host-bound (small batches); ignored for UniPC, step
@@ -170,6 +178,10 @@ class PipelineBase:
     def garment_features(self, ref_image_latents: torch.Tensor, cloth_proj_embed: torch.Tensor) -> Dict[str, torch.Tensor]:
         """Garment UNet once at t = 0 with the 16 resampler tokens as context; returns the (post-LayerNorm)
         input of every attention layer, [1, M, C] each (IMAGDressing_v1_pipeline.py:465-480)."""
+        with ops.tuning_scope(**(getattr(self, "_tuning", None) or {})):
+            return self._garment_features(ref_image_latents, cloth_proj_embed)
+
+    def _garment_features(self, ref_image_latents, cloth_proj_embed):
         dt = self.reference_unet.dtype
         x = nchw_to_nhwc8(ref_image_latents[:1].to(self.device), dt)
         ehs = cloth_proj_embed[-1:].to(device=self.device, dtype=dt).contiguous()     # the cond half ([1] of the CFG pair)
@@ -181,7 +193,12 @@ class PipelineBase:
 
     # ---- the loop ----
     @torch.no_grad()
-    def denoise(self, *, latents: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: torch.Tensor,
+    def denoise(self, **kw) -> torch.Tensor:
+        """:meth:`_denoise` inside this pipeline's tuning scope (:meth:`set_tuning`)."""
+        with ops.tuning_scope(**(getattr(self, "_tuning", None) or {})):
+            return self._denoise(**kw)
+
+    def _denoise(self, *, latents: torch.Tensor, prompt_embeds: torch.Tensor, negative_prompt_embeds: torch.Tensor,
                 sa_hidden_states: Dict[str, torch.Tensor], num_inference_steps: int, guidance_scale: float,
                 control: Optional[dict] = None, inpaint: Optional[dict] = None,
                 callback: Optional[Callable] = None, callback_steps: int = 1, trace: Optional[list] = None,

@@ -84,10 +84,16 @@ class PendingModel:
         if device is None:
             return self
         eng = self.__dict__.get("_engine")              # (already built by a first use: same engine, `.to(device)` is then a no-op check)
-        return eng.to(device=device) if eng is not None else self._build(device)
+        if eng is None:                                 # keep it: a caller that holds on to the HANDLE must reach the same engine later
+            eng = self.__dict__["_engine"] = self._build(device)
+            return eng
+        return eng.to(device=device)
 
     def _build(self, device="cuda"):
         dtype = self.__dict__.get("_dtype") or torch.float16      # the reference's dtype (inference_IMAGdressing.py:42-52)
+        if self._sd is None:
+            raise RuntimeError(f"{self._cls.__name__}.from_pretrained(...) handle: the engine was already built (its weights were handed over); "
+                               "use the engine `.to(device=...)` returned")
         eng = self._cls(self._sd, self._engine_config, device, dtype)
         self.__dict__["_sd"] = None
         return eng
@@ -96,7 +102,7 @@ class PendingModel:
         """First use of the engine surface (``set_attn_processor``, ``load_state_dict``, ``attn_processors``, a call ...) on a handle that
         has its element type but never got a device: the engine is built NOW on the current HIP device ("on first use", as ``to``'s
         docstring says) and the handle forwards to it from then on.  Without any ``.to`` / ``torch_dtype`` the handle stays inert."""
-        if name.startswith("__") or "_dtype" not in self.__dict__:
+        if name.startswith("_") or "_dtype" not in self.__dict__:        # (private probes such as hasattr(h, "_hf_hook") must not build an engine)
             raise AttributeError(f"{self._cls.__name__}.from_pretrained(...) handle has no attribute {name!r}: call "
                                  ".to(dtype=..., device=...) first (that is where the MI355X engine is built)")
         eng = self.__dict__.get("_engine")

@@ -151,6 +151,54 @@ GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record th
 GEMM_EVENT_HOOK = None     # tools/insitu_conv.py sets this to a dict: every conv_gemm launch is bracketed by HIP events, keyed by (shape key, cfg, split)
 _GEMM_TABLE = None
 
+# ---- per-call tuning (include/imagdressing_hip.h: IMD_TUNING_PER_CALL) ----------------------------------------------------------------
+# imd_set_tuning() is process-wide.  Inside ``with tuning_scope(...)`` every params block built by this module carries the scope's choice in
+# its `flags` field instead, so two pipelines of one process can run different settings (PipelineBase.set_tuning) and nothing global changes.
+TUNING_PER_CALL = 0x40000000
+_TUNING = None             # None | dict(attn_variant=int|None, attn_xcd=bool|None, gemm_flags=int|None)
+
+
+class tuning_scope:
+    """``with ops.tuning_scope(attn_variant=12, gemm_flags=3): ...`` -- head-dim-40 attention variant (knob 0), XCD-aware attention work
+    order (knob 1) and bits 0..4 of the GEMM tuning flags (knob 2) for the launches issued inside, per call.  Scopes nest; None = inherit."""
+
+    def __init__(self, attn_variant=None, attn_xcd=None, gemm_flags=None):
+        self.new = dict(attn_variant=attn_variant, attn_xcd=attn_xcd, gemm_flags=gemm_flags)
+
+    def __enter__(self):
+        global _TUNING
+        self.prev = _TUNING
+        merged = dict(self.prev or {})
+        merged.update({k: v for k, v in self.new.items() if v is not None})
+        _TUNING = merged if any(v is not None for v in merged.values()) else None
+        return self
+
+    def __exit__(self, *exc):
+        global _TUNING
+        _TUNING = self.prev
+        return False
+
+
+def _gemm_call_flags() -> int:
+    t = _TUNING
+    if t is None or t.get("gemm_flags") is None:
+        return 0
+    return TUNING_PER_CALL | (int(t["gemm_flags"]) & 31)
+
+
+def _attn_call_flags() -> int:
+    t = _TUNING
+    if t is None or (t.get("attn_variant") is None and t.get("attn_xcd") is None):
+        return 0
+    v = int(t.get("attn_variant") or 0)
+    if not 0 <= v <= 54:
+        raise L.ImdError(f"tuning_scope: attention variant {v} out of range")
+    if t.get("attn_xcd") is None:           # inherit the process-wide order
+        xcd = bool(L.load().imd_get_tuning(1))
+    else:
+        xcd = bool(t["attn_xcd"])
+    return TUNING_PER_CALL | v | (0 if xcd else 256)
+
 
 def _gemm_table() -> dict:
     global _GEMM_TABLE
@@ -191,6 +239,7 @@ def conv_gemm(
     ensure_device(x.device)
     K = taps * Cin
     p = L.ConvGemmParams()
+    p.flags = _gemm_call_flags()
     dt = x.dtype
     p.dtype = _code(x, "x")
     p.x = _dev(x, dt, "x")
@@ -258,7 +307,7 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg in (12, 13, 14, 15) and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
-            if cfg in (16, 17, 19, 25, 27) and not lib.imd_gemm_dma_supported(C.byref(p)):
+            if cfg in (16, 17, 19, 25, 27, 30, 31, 32) and not lib.imd_gemm_dma_supported(C.byref(p)):
                 cfg, split_k = -1, 0
             if (cfg in (18, 20) and (taps != 9 or Cin % 32 or stride not in (1, 2) or gn is not None)) or \
                     (cfg in (26, 28) and (taps != 9 or Cin % 64 or stride not in (1, 2) or gn is not None)):
@@ -465,6 +514,7 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
     p.out_ld = H * D if out_ld is None else out_ld
     p.causal = int(causal)
     p.k_pad_one = int(bool(k_pad_one))
+    p.flags = _attn_call_flags()
     ret = out
     if proj is not None:
         pw, pb, pres, pout = proj

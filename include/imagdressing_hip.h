@@ -45,6 +45,14 @@ typedef struct imd_heads_dest {
     float scale;   /* multiplied in fp32 before rounding (softmax scale * log2 e folded into Q) */
 } imd_heads_dest;
 
+/* Per-call tuning (ABI v8, additive): `flags` of imd_conv_gemm_params / imd_attn_params is normally ignored on entry and filled in by the
+ * library from the process-wide knobs of imd_set_tuning().  A caller that sets IMD_TUNING_PER_CALL in it chooses for THIS call only:
+ *   imd_conv_gemm:  bits 0..4 = bits 0..4 of tuning knob 2 (tap-inner K order, weight loads past L1, XCD-aware tile order, grouped order)
+ *   imd_attention:  bits 0..7 = head-dim-40 kernel variant (tuning knob 0; 0 = the process-wide value), bit 8 = 1: plain work order
+ *                   (tuning knob 1 = 0)
+ * so two pipelines in one process can run different settings without touching global state (imagdressing_amd.ops.tuning_scope). */
+#define IMD_TUNING_PER_CALL 0x40000000
+
 typedef struct imd_conv_gemm_params {
     uint32_t struct_bytes; /* sizeof(imd_conv_gemm_params) in the caller's view (ABI v8); checked on entry */
     const uint16_t* x; /* NHWC activations (pixel stride x_pix_stride) or [M, K] rows */
@@ -68,7 +76,7 @@ typedef struct imd_conv_gemm_params {
     int split_k;         /* K slices (<= 1: none); > 1 needs splitk_ws and a row-major epilogue */
     float* splitk_ws;    /* split_k * M * N floats of scratch */
     uint32_t x_bytes, w_bytes; /* filled in by the library (buffer-descriptor extents) */
-    int flags;           /* filled in by the library (tuning bits) */
+    int flags;           /* filled in by the library (tuning bits); on entry: 0, or IMD_TUNING_PER_CALL | per-call tuning bits (see above) */
     /* fused GroupNorm(+SiLU) prologue (cfg 5 only): x is normalised as x*gn_a[b][c] + gn_b[b][c] (then SiLU when
      * gn_silu) while it is staged; coefficients come from imd_groupnorm_coeffs().  NULL: plain convolution. */
     const float* gn_a;
@@ -79,11 +87,16 @@ typedef struct imd_conv_gemm_params {
     int* splitk_counters; /* split_k > 1 only.  NULL: the K slices are summed by a second launch (fixed order).  Otherwise >=
                           * IMD_SPLITK_COUNTERS ints that are ZERO on entry and are left zero: every output tile's last-arriving
                           * workgroup sums the slices itself, in the same fixed order (bit-identical results, one launch less) */
-    /* GroupNorm statistics of the OUTPUT produced in the epilogue (cfg 5 / 22 / 23 with split_k == 1, or the finish launch of a K-sliced problem:
-     * imd_conv_gemm_stats_parts(); row-major 16-bit output, N % gn_stats_groups == 0): every workgroup writes the fp32 (sum, sum of squares) of its tile's final values per group to
-     * gn_stats_out[((b * nparts + part) * G + g) * 2], part = (pixel tile of the image) * n_tiles + channel tile, nparts =
-     * imd_conv_patch_stats_parts(); groups outside the tile get zeros.  The next imd_groupnorm on that tensor passes the buffer
-     * as `partial` with `nparts` and skips its statistics pass (ResnetBlock2D: conv1 -> norm2, conv2 -> the next block's norm). */
+    /* GroupNorm statistics of the OUTPUT (row-major 16-bit output, N % gn_stats_groups == 0, >= 8 channels per group): the fp32 (sum, sum of
+     * squares) per group of the FINAL (rounded) values, written to gn_stats_out[((b * nparts + part) * G + g) * 2].  Size the buffer with
+     * nparts = imd_conv_gemm_stats_parts(p, cfg) -- NOT imd_conv_patch_stats_parts() -- because the layout depends on who writes it:
+     *   - tile configs 5 / 22 / 23 / 29 with split_k == 1: the halo-patch kernel's own epilogue, part = (pixel tile of the image) * n_tiles +
+     *     channel tile; groups outside a tile get zeros;
+     *   - ANY K-sliced launch that finishes with the second launch (split_k > 1, splitk_counters == NULL): the finish launch, part = a block
+     *     of consecutive pixels of image b (all channels), nparts = ceil(HW / rows per part).
+     * imd_conv_gemm_stats_parts() answers 0 when this (p, cfg) cannot produce them; a launch that asks anyway is refused.  The next
+     * imd_groupnorm on that tensor passes the buffer as `partial` with `nparts` and skips its statistics pass (ResnetBlock2D: conv1 -> norm2,
+     * conv2 -> the next block's norm). */
     float* gn_stats_out;
     int gn_stats_groups;
 } imd_conv_gemm_params;
@@ -103,7 +116,7 @@ typedef struct imd_attn_params {
     int L2, L2P, kv2_bdiv;
     int out_ld;
     int dtype;
-    int flags;           /* filled in by the library (tuning bits) */
+    int flags;           /* filled in by the library (tuning bits); on entry: 0, or IMD_TUNING_PER_CALL | per-call tuning bits (see above) */
     int causal;          /* 1: query i attends keys 0..i of the first key set only (CLIP text encoder); needs k2 == NULL, D != 40 */
     int k_pad_one;       /* 1: the caller guarantees that pad column D of EVERY K row (k1 and k2) holds 1.0 (D < DPK only, i.e.
                           * D = 40: the slot through which the deferred row maximum enters the QK^T MFMA).  The kernels that

@@ -480,3 +480,27 @@ def test_engine_attention_hands_unnormalised_states_only_to_processors_that_opte
     monkeypatch.setattr(ops, "FUSED_LN", False)                                 # the A/B switch restores the two-launch path
     a(h, encoder_hidden_states=ehs, residual=h, layernorm=(norm, 1e-5))
     assert calls == ["ln"] and a.processor.ln is None
+
+
+def test_tuning_scope_builds_per_call_flags():
+    """ops.tuning_scope: the per-call tuning word that rides in the params blocks' `flags` (IMD_TUNING_PER_CALL, include/imagdressing_hip.h);
+    scopes nest, None inherits, leaving a scope restores the outer one; no library knob is touched."""
+    import re
+    from imagdressing_amd import ops
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "imagdressing_hip.h")).read()
+    assert int(re.search(r"#define IMD_TUNING_PER_CALL (0x[0-9a-fA-F]+)", hdr).group(1), 16) == ops.TUNING_PER_CALL
+    assert ops._gemm_call_flags() == 0 and ops._attn_call_flags() == 0
+    with ops.tuning_scope(gemm_flags=3):
+        assert ops._gemm_call_flags() == ops.TUNING_PER_CALL | 3 and ops._attn_call_flags() == 0
+        with ops.tuning_scope(attn_variant=12, attn_xcd=False):
+            assert ops._gemm_call_flags() == ops.TUNING_PER_CALL | 3
+            assert ops._attn_call_flags() == ops.TUNING_PER_CALL | 12 | 256
+            with ops.tuning_scope(attn_xcd=True, gemm_flags=23):
+                assert ops._attn_call_flags() == ops.TUNING_PER_CALL | 12
+                assert ops._gemm_call_flags() == ops.TUNING_PER_CALL | 23
+        assert ops._attn_call_flags() == 0
+    assert ops._TUNING is None
+    with pytest.raises(ops.L.ImdError):
+        with ops.tuning_scope(attn_variant=99):
+            ops._attn_call_flags()
+    assert ops._TUNING is None

@@ -84,7 +84,8 @@ def test_linear_epilogues(ops, dt):
 
 @DTS
 @pytest.mark.parametrize("M,N,K,split,cfg", [(512, 1280, 11520, 6, 0), (200, 320, 2304, 3, 2), (2048, 132, 4096, 4, 1), (64, 64, 8192, 8, -1), (300, 640, 2560, 5, 6), (130, 64, 4096, 7, 7), (600, 384, 2048, 3, 9), (520, 520, 1024, 2, 10),
-                                                  (512, 1280, 5120, 3, 17), (300, 132, 2048, 4, 17), (512, 1280, 5120, 3, 25), (300, 132, 2048, 4, 27)])
+                                                  (512, 1280, 5120, 3, 17), (300, 132, 2048, 4, 17), (512, 1280, 5120, 3, 25), (300, 132, 2048, 4, 27),
+                                                  (512, 1280, 5120, 3, 30), (300, 132, 2048, 4, 31), (1000, 640, 2560, 2, 32), (4096, 640, 2560, 5, 30)])
 def test_linear_split_k(ops, M, N, K, split, cfg, dt):
     """K slices into fp32 slabs + fixed-order finish kernel == unsplit result (bias + residual + SiLU epilogue)."""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
@@ -286,11 +287,12 @@ def test_row_qkv(ops, ln, dt):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 320, 320), (1000, 2560, 640), (77, 64, 768), (520, 1284, 1280), (2048 + 19, 520, 128)])
-@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27, 30, 31, 32])
 @DTS
 def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
     """tile configs 16 (256 x 256 x 64, two stages), 17 and 19 (128 x 128 x 32, three- / four-stage ring, round 3), 25 and 27 (128 x 128 x 64:
-    128-byte rows, two / three stages, round 4): both operands by LDS-DMA (gemm_dma.hip) == x W^T + b, with the shared epilogues"""
+    128-byte rows, two / three stages, round 4), 30 / 31 / 32 (gemm_dma256.hip, round 5: 256-row tiles, persistent item loop, epilogue from
+    registers): both operands by LDS-DMA == x W^T + b, with the shared epilogues"""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
     base = x.float() @ w.float().t() + b
     assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=cfg), base, what="gemm_dma")
@@ -305,7 +307,7 @@ def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
         ops.linear(dev(rnd(1, 64, 72).to(dt)), dev(rnd(2, 64, 72).to(dt)), cfg=cfg)           # K % 64 != 0: refused
 
 
-@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27, 30, 31, 32])
 @DTS
 def test_gemm_dma_head_split(ops, dt, cfg):
     """head-split q / k / v epilogue through tile config 16 (the 32x32-level projection: 8 heads x 80)"""
@@ -319,6 +321,48 @@ def test_gemm_dma_head_split(ops, dt, cfg):
     assert_close(q[..., :D], 0.3 * ref[:, :, 0].permute(0, 2, 1, 3), what="Q")
     assert_close(k[..., :D], ref[:, :, 1].permute(0, 2, 1, 3), what="K")
     assert_close(vt[:, :, :D, :HW], ref[:, :, 2].permute(0, 2, 3, 1), what="V^T")
+
+
+@pytest.mark.parametrize("M,N,K,act,split", [(8192, 5120, 640, "geglu", 1), (2048, 10240, 1280, "geglu", 1), (8192, 640, 2560, "res", 1),
+                                             (8192, 640, 2560, "res", 2), (8192 + 70, 1920, 640, "heads", 1)])
+@pytest.mark.parametrize("cfg", [30, 32])
+@DTS
+def test_gemm_dma256_persistent_item_loop(ops, M, N, K, act, split, cfg, dt):
+    """gemm_dma256.hip at the feed-forward shapes it was written for (BASELINE configs[1], batch 4: GEGLU 8192 x 5120 x 640 and
+    2048 x 10240 x 1280, FF-out 8192 x 640 x 2560 with and without K slices, the 32x32-level q/k/v projection with a ragged row count):
+    640 ... 1280 (tile, slice) items walked by 256 persistent workgroups -- several items per workgroup, the operand ring running across item
+    boundaries, results leaving from registers.  Against fp32 torch, and BIT-identical to the 128 x 128 LDS-DMA tiles (tile config 25: same
+    MFMA instruction, same ascending K order, same epilogue arithmetic) wherever no K slices are involved."""
+    x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N)
+    base = x.float() @ w.float().t() + b
+    if act == "geglu":
+        out = ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_GEGLU, cfg=cfg)
+        assert_close(out, base[:, 0::2] * F.gelu(base[:, 1::2]), what="geglu")
+        assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), act=ops.ACT_GEGLU, cfg=25)), "differs from the 128 x 128 tiles"
+    elif act == "res":
+        res = rnd(4, M, N).to(dt)
+        out = ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=cfg, split_k=split)
+        assert_close(out, base + res.float(), what="residual")
+        if split == 1:
+            assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=25, split_k=1)), "differs from the 128 x 128 tiles"
+        else:
+            assert torch.equal(out, ops.linear(dev(x), dev(w), dev(b), res=dev(res), cfg=25, split_k=split)), "K slices differ from the 128 x 128 tiles'"
+    else:
+        B, H, D = 2, 8, 80
+        HW, Cc = M // B, N // 3
+        DPK, DPV = ops.attn_padded_dims(D); LP = ops.pad64(HW)
+        outs = []
+        for c in (cfg, 25):
+            q = torch.zeros(B, H, HW, DPK, dtype=dt, device="cuda"); k = torch.zeros_like(q); vt = torch.zeros(B, H, DPV, LP, dtype=dt, device="cuda")
+            ops.conv_gemm(dev(x), dev(w), M=M, N=N, Cin=K, Hin=HW, Win=1, Hout=HW, Wout=1, cfg=c,
+                          heads=dict(C=Cc, H=H, D=D, dests=[(q, 0, DPK, HW, 0.3), (k, 0, DPK, HW, 1.0), (vt, 1, DPV, LP, 1.0)]))
+            outs.append((q, k, vt))
+        ref = F.linear(x.float(), w.float()).view(B, HW, 3, H, D)
+        assert_close(outs[0][0][..., :D], 0.3 * ref[:, :, 0].permute(0, 2, 1, 3), what="Q")
+        assert_close(outs[0][2][:, :, :D, :HW], ref[:, :, 2].permute(0, 2, 3, 1), what="V^T")
+        for a, b2 in zip(outs[0], outs[1]):
+            assert torch.equal(a, b2), "head-split output differs from the 128 x 128 tiles"
+    assert torch.isfinite(out.float()).all() if act != "heads" else True
 
 
 @DTS
@@ -862,6 +906,32 @@ def test_attention_d40_unchecked_steps_rerun_on_overflow(ops, N, L1, L2, where, 
     if where == "interior":
         assert torch.equal(out13[:, :256], out12[:, :256])
     assert_close(out13, out12, atol=2e-2, rtol=2e-2, what="variant 13 vs 12 under large scores")
+
+
+@DTS
+def test_per_call_tuning_matches_the_process_wide_knobs(ops, dt):
+    """IMD_TUNING_PER_CALL (ops.tuning_scope): the head-dim-40 variant / work order and the GEMM tuning bits chosen per call give exactly what
+    the process-wide knobs of imd_set_tuning give, and leave those knobs alone."""
+    lib = ops.L.load()
+    before = [lib.imd_get_tuning(k) for k in range(3)]
+    for variant in (7, 12):
+        ref, _ = _run_d40_variant(ops, 640, 1000, 520, True, variant, 3.0, dt)
+        D, H, B, N, L1 = 40, 8, 2, 640, 1000
+        with ops.tuning_scope(attn_variant=variant):
+            got, _ = _run_d40_variant(ops, N, L1, 520, True, before[0], 3.0, dt)      # (the helper sets knob 0 to the shipped value: the scope must win)
+        assert torch.equal(got, ref), f"per-call variant {variant}"
+    x = rnd(1, 2, 32, 32, 64).to(dt); w = rnd(2, 128, 64, 3, 3, scale=(9 * 64) ** -0.5).to(dt); b = rnd(3, 128)
+    wp = dev(pack_conv(w))
+    ops.L.check(lib.imd_set_tuning(2, 0))
+    try:
+        plain = ops.conv2d_nhwc(dev(x), wp, dev(b), cfg=0)
+    finally:
+        ops.L.check(lib.imd_set_tuning(2, before[2]))
+    with ops.tuning_scope(gemm_flags=0):
+        scoped = ops.conv2d_nhwc(dev(x), wp, dev(b), cfg=0)
+    assert torch.equal(plain, scoped)
+    assert_close(scoped, F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1), what="conv under a tuning scope")
+    assert [lib.imd_get_tuning(k) for k in range(3)] == before
 
 
 @pytest.mark.parametrize("pad_one", [True, False])

@@ -159,3 +159,41 @@ def test_unet_timestep_fixture_is_complete():
         for a, b in zip(outs, outs[1:]):
             assert (a - b).abs().max() > 0.05
     assert {"ctrl", "lora0", "ip0", "ehs_c", "pose"} <= set(g["ipa_controlnet"]["digests"])
+
+
+def test_trajectory_fixture_is_complete():
+    """tests/golden/trajectory.pt (oracle/make_golden.py trajectory): every case of tests/trajectory_fixture.py::CASES with one final latent
+    per seed and the kept intermediate latents, finite, seeds really differ, the trajectory really moves between kept steps, the inpainting
+    case keeps the original latents outside the mask, and the cheap input digests regenerate (the 859.5 M-parameter state dicts are
+    digest-checked by the GPU tests, which have to build them anyway)."""
+    import os
+    from tests import trajectory_fixture as TF
+    g = torch.load(TF.FILE, weights_only=False)
+    assert set(TF.CASES) <= set(g)
+    for name, spec in TF.CASES.items():
+        c = g[name]
+        nseed = len(spec["seeds"])
+        assert c["final"].shape == (nseed, 4, spec["lh"], spec["lw"]) and torch.isfinite(c["final"]).all()
+        assert set(c["steps"]) == set(spec["keep"])
+        prev = None
+        for k in sorted(spec["keep"]):
+            z = c["steps"][k]
+            assert z.shape == c["final"].shape and torch.isfinite(z).all()
+            if prev is not None:
+                assert (z - prev).abs().max() > 1e-2
+            prev = z
+        assert torch.equal(c["steps"][spec["steps"] - 1], c["final"])          # the last kept step IS the final latent
+        if nseed > 1:
+            assert (c["final"][0] - c["final"][1]).pow(2).mean().sqrt() > 0.2 * c["final"].std()
+        d = c["digests"]
+        assert d["ne"] == TF.digest(TF.rnd(3, 1, 77, 768, scale=0.5)) and d["clip"] == TF.digest(TF.rnd(20, 1, 257, 1280, scale=0.5))
+        assert d["refl"] == TF.digest(TF.rnd(13, 1, 4, spec["lh"], spec["lw"]))
+        assert d["resampler"] == TF.digest(TF.resampler_state_dict(3)["latents"])
+    # configs[0] and configs[1] start from the same noise (seed 42) and take different schedules: the trajectories differ
+    assert (g["configs0_20step"]["final"][0] - g["configs1_50step"]["final"][0]).abs().max() > 1e-2
+    # inpainting: outside the mask the final latent is the original image latent (..._controlnet_inpainting.py:494-500)
+    spec = TF.CASES["configs4_10step"]
+    lh, lw = spec["lh"], spec["lw"]
+    m = torch.zeros(1, 1, lh, lw); m[:, :, int(lh * 0.184): int(lh * 0.816), int(lw * 0.184): int(lw * 0.816)] = 1.0
+    keep = (m == 0).expand(1, 4, -1, -1)
+    assert torch.allclose(g["configs4_10step"]["final"][keep], TF.rnd(17, 1, 4, lh, lw)[keep], atol=1e-5)

@@ -19,6 +19,14 @@ from tests.trajectory_fixture import CASES, FILE  # noqa: E402
 BARS = {torch.float16: dict(rel_rms=1e-2, max_sigma=0.1), torch.bfloat16: dict(rel_rms=6e-2, max_sigma=0.5)}
 
 
+def _record(dtype, res):
+    """measured figures -> gpurun_out/trajectory_parity.jsonl (written BEFORE the bars are applied: a failing run leaves its numbers)"""
+    import json
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/trajectory_parity.jsonl", "a") as f:
+        f.write(json.dumps(dict(dtype=str(dtype), **res)) + "\n")
+
+
 def _check(ent, bar, what):
     assert ent["rel_rms"] <= bar["rel_rms"] and ent["max_abs_over_sigma"] <= bar["max_sigma"], (what, ent, bar)
 
@@ -42,6 +50,7 @@ def test_full_width_trajectory_vs_committed_oracle(gold, dtype):
     for c in ("configs0_20step", "configs1_50step"):
         assert c in gold, f"{c} missing from trajectory.pt"
     res = measure_trajectory_parity(torch.device("cuda"), dtype, cases=("configs0_20step", "configs1_50step"))
+    _record(dtype, res)
     bar = BARS[dtype]
     for name in ("configs0_20step", "configs1_50step"):
         spec = CASES[name]
@@ -56,10 +65,6 @@ def test_full_width_trajectory_vs_committed_oracle(gold, dtype):
     for k, v in b4.items():
         if k.startswith("row"):
             _check(v, bar, ("batch4", k))
-    import json
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/trajectory_parity.jsonl", "a") as f:
-        f.write(json.dumps(dict(dtype=str(dtype), **res)) + "\n")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
@@ -72,6 +77,7 @@ def test_full_width_trajectory_other_configs_vs_committed_oracle(gold, name, dty
     if name not in gold:
         pytest.fail(f"{name} missing from trajectory.pt")
     res = measure_trajectory_parity(torch.device("cuda"), dtype, cases=(name,), batch4=False, graph=False)
+    _record(dtype, res)
     bar = BARS[dtype]
     spec = CASES[name]
     for seed in spec["seeds"]:
@@ -80,7 +86,3 @@ def test_full_width_trajectory_other_configs_vs_committed_oracle(gold, name, dty
         _check(ent["final"], bar, (name, seed, "final"))
         for k in spec["keep"]:
             _check(ent[f"step{k}"], bar, (name, seed, k))
-    import json
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/trajectory_parity.jsonl", "a") as f:
-        f.write(json.dumps(dict(dtype=str(dtype), **res)) + "\n")

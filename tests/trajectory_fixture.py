@@ -45,7 +45,27 @@ def resampler_state_dict(seed=3):
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
 
+_INPUT_CACHE = {}          # (kind, lh, lw) -> CPU tensors; two dtypes in one process share the 2 x 3.4 GB of seeded fp32 weights
+
+
+def clear_input_cache():
+    _INPUT_CACHE.clear()
+
+
 def trajectory_inputs(kind, lh, lw, base=None):
+    """Cached wrapper of :func:`_trajectory_inputs` (call :func:`clear_input_cache` when done)."""
+    key = (kind, lh, lw)
+    if key not in _INPUT_CACHE:
+        if base is None:
+            for (k2, h2, w2), d2 in _INPUT_CACHE.items():        # another family on the same latent: share the UNet / garment-UNet state dicts
+                if (h2, w2) == (lh, lw):
+                    base = {k: d2[k] for k in ("sd", "x", "ehs", "rw", "sa", "names", "digests", "sd_ref", "resampler_sd") if k in d2}
+                    break
+        _INPUT_CACHE[key] = _trajectory_inputs(kind, lh, lw, base)
+    return _INPUT_CACHE[key]
+
+
+def _trajectory_inputs(kind, lh, lw, base=None):
     """CPU tensors of one trajectory family: the denoising UNet (seed 0; shared with unet_forward_inputs), the garment UNet (seed 1),
     to_k_ref / to_v_ref (seed 7), the Resampler (seed 3), prompt / negative text states, garment CLIP states [1, 257, 1280] and garment
     latent, plus per kind the configs[2] additions (tests/unet_fixture.py::ipa_controlnet_forward_inputs) or the inpainting ones
@@ -54,8 +74,10 @@ def trajectory_inputs(kind, lh, lw, base=None):
     d = dict(base) if base is not None else unet_forward_inputs(lh, lw)
     if kind == "ipa_controlnet" and "ctrl_sd" not in d:
         d = ipa_controlnet_forward_inputs(base=d)
-    d["sd_ref"] = E.random_state_dict(E.unet_param_shapes(E.SD15_CONFIG), 1)
-    d["resampler_sd"] = resampler_state_dict(3)
+    if "sd_ref" not in d:
+        d["sd_ref"] = E.random_state_dict(E.unet_param_shapes(E.SD15_CONFIG), 1)
+    if "resampler_sd" not in d:
+        d["resampler_sd"] = resampler_state_dict(3)
     d["pe"] = d["ehs"]                                             # rnd(2, 1, 77, 768) * 0.5
     d["ne"] = rnd(3, 1, 77, 768, scale=0.5)
     d["clip"] = rnd(20, 1, 257, 1280, scale=0.5)
