@@ -457,7 +457,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 22: *bm = 128; *bn = 160; return 0;
         case 23: *bm = 256; *bn = 160; return 0;
         case 24: *bm = 512; *bn = 64; return 0;
-        case 10: case 16: case 32: *bm = 256; *bn = 256; return 0;
+        case 10: case 16: *bm = 256; *bn = 256; return 0;
         case 17: case 18: case 19: case 20: case 25: case 26: case 27: case 28: *bm = 128; *bn = 128; return 0;
         case 11: *bm = 128; *bn = 320; return 0;
         default: return 1;
@@ -485,7 +485,7 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28) || (cfg >= 30 && cfg <= 32)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28) || (cfg >= 30 && cfg <= 31)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
@@ -557,6 +557,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         p.flags |= imd_gemm_pick_order(p, (p.N + bn - 1) / bn);
         p.flags |= gf & 16;
     }
+    p.flags |= gf & 224;       // bits 5..7: timing ablations of gemm_dma256.hip (A/B only; WRONG results when set)
     if (p.split_k <= 1) p.splitk_counters = nullptr;
     // GroupNorm statistics of the output (ABI v6+): the halo-patch kernels' un-split epilogues (tile configs 5 / 22 / 23 / 29) and the finish
     // launch of any K-sliced problem produce them (imd_conv_gemm_stats_parts_of); every other request is an
@@ -630,8 +631,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             if (rc) return rc;
             return launch_splitk_finish(p, s, "conv_img split-K finish");
         }
-        case 30: case 31: case 32: {   // 256-row LDS-DMA tiles, register epilogue (gemm_dma256.hip): 30 = 256 x 128 x 64, three stages, persistent over
-                                       // (tile, K slice) items; 31 = the same with one item per workgroup; 32 = 256 x 256 x 64, two stages, persistent
+        case 30: case 31: {   // LDS-DMA tiles with producer / consumer waves and a register epilogue (gemm_dma256.hip): 30 = 256 x 128 x 64, three stages,
+                              // persistent over (tile, K slice) items; 31 = the same with one item per workgroup
             p.splitk_counters = nullptr;
             int rc = imd_launch_gemm_dma256(p, cfg - 30, s);
             if (rc || p.split_k <= 1) return rc;

@@ -84,7 +84,9 @@ __device__ __forceinline__ void load_col_addends(const ConvGemmParams& p, int bi
 template <bool F16>
 __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int m, int n, int nv, int HWo, bool use_pre = false,
                                           float4 pre0 = float4{0, 0, 0, 0}, float4 pre1 = float4{0, 0, 0, 0}, bool use_rpre = false,
-                                          uint4 rpre = uint4{0, 0, 0, 0}) {
+                                          uint4 rpre = uint4{0, 0, 0, 0}, uint4* pk_out = nullptr) {
+    // pk_out (gemm_dma256.hip): a row-major 16-bit result -- 8 channels, or the 4 GEGLU outputs in .x / .y -- is handed back packed instead of
+    // being stored; the caller stores it (after a lane transpose that makes the stores whole lines).  Other output forms ignore it.
     using E = El<F16>;
     const int bi = m / HWo;
     float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, r0 = b0, r1 = b0;
@@ -148,6 +150,7 @@ __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int
         const uint32_t o0 = E::pack2(v[0] * gelu_erf_f(v[1]), v[2] * gelu_erf_f(v[3]));
         if (full) {
             const uint32_t o1 = E::pack2(v[4] * gelu_erf_f(v[5]), v[6] * gelu_erf_f(v[7]));
+            if (pk_out) { pk_out->x = o0; pk_out->y = o1; return; }
             *reinterpret_cast<uint2*>(dst) = make_uint2(o0, o1);
         } else {
             *reinterpret_cast<uint32_t*>(dst) = o0;
@@ -158,6 +161,7 @@ __device__ __forceinline__ void epilogue8(const ConvGemmParams& p, float* v, int
         if (full) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
         bf16_t* dst = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.out_ld + n;
+        if (full && pk_out) { *pk_out = pack8<F16>(v); return; }
         if (full) *reinterpret_cast<uint4*>(dst) = pack8<F16>(v);
         else *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v[0], v[1]), E::pack2(v[2], v[3]));
     }

@@ -51,7 +51,7 @@ int imd_launch_row_qkv(const ConvGemmParams& p, int ln, float ln_eps, hipStream_
 bool imd_gemm_dma_supported(const ConvGemmParams& p);                                       // gemm_dma.hip
 int imd_launch_gemm_dma(const ConvGemmParams& p, hipStream_t s);
 int imd_launch_gemm_dma128(const ConvGemmParams& p, int stages, hipStream_t s);      // stages: 3 | 4 ring stages
-int imd_launch_gemm_dma256(const ConvGemmParams& p, int form, hipStream_t s);        // gemm_dma256.hip: 0 = 256x128 persistent, 1 = 256x128, 2 = 256x256 persistent (tile configs 30 / 31 / 32)
+int imd_launch_gemm_dma256(const ConvGemmParams& p, int form, hipStream_t s);        // gemm_dma256.hip: 0 = 256x128 persistent, 1 = 256x128 one item per workgroup (tile configs 30 / 31)
 bool imd_conv_dma_supported(const ConvGemmParams& p);                         // gemm_dma.hip: 128 x 128 x 32, 3-stage ring (tile config 17)
 int imd_launch_ff_geglu(const imd_ff_params& p, hipStream_t s);                              // ff_fused.hip
 int imd_launch_attention(const AttnParams& p, hipStream_t s);

@@ -307,7 +307,7 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg in (12, 13, 14, 15) and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
-            if cfg in (16, 17, 19, 25, 27, 30, 31, 32) and not lib.imd_gemm_dma_supported(C.byref(p)):
+            if cfg in (16, 17, 19, 25, 27, 30, 31) and not lib.imd_gemm_dma_supported(C.byref(p)):
                 cfg, split_k = -1, 0
             if (cfg in (18, 20) and (taps != 9 or Cin % 32 or stride not in (1, 2) or gn is not None)) or \
                     (cfg in (26, 28) and (taps != 9 or Cin % 64 or stride not in (1, 2) or gn is not None)):

@@ -11,6 +11,7 @@ ap.add_argument("--force", nargs="*", default=[]); ap.add_argument("--top", type
 ap.add_argument("--taps", type=int, default=0, help="only keys with this many taps (9 | 1)")
 ap.add_argument("--batch", type=int, default=4, help="images per batch (1: the latency shapes)")
 ap.add_argument("--grep", default="", help="only keys containing this text")
+ap.add_argument("--width", type=int, default=512); ap.add_argument("--height", type=int, default=512)
 a = ap.parse_args()
 tab = ops._gemm_table()
 for f in a.force:
@@ -21,9 +22,9 @@ for f in a.force:
     tab[key] = ent
 dev = torch.device("cuda", 0)
 pipe = bench.build_pipeline(dev, torch.bfloat16, 0)
-inp = bench.synthetic_inputs(512, 512, a.batch, dev, torch.bfloat16, 0, 1)
+inp = bench.synthetic_inputs(a.width, a.height, a.batch, dev, torch.bfloat16, 0, 1)
 def run():
-    return pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=512, height=512, num_inference_steps=a.steps,
+    return pipe(prompt=None, null_prompt=None, negative_prompt=None, ref_image=None, width=a.width, height=a.height, num_inference_steps=a.steps,
                 guidance_scale=7.5, num_images_per_prompt=a.batch, output_type="latent", **inp).images
 run(); torch.cuda.synchronize()
 ops.GEMM_EVENT_HOOK = {}
