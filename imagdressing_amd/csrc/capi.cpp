@@ -101,7 +101,7 @@ int imd_set_tuning(int knob, int value) {
 #endif
             g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
-        case 2: g_gemm_flags = value & 1023; return 0;   // (bit 8: row_linear staged epilogue, bit 9: halo-patch conv staged through registers; A/B only)
+        case 2: g_gemm_flags = value & 2047; return 0;   // (bit 8: row_linear staged epilogue, bit 9: halo-patch conv staged through registers, bit 10: row kernels store 8 bytes per lane; A/B only)
         default: return imd_set_error("set_tuning: unknown knob %d", knob);
     }
 }

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(512, 1) void ff_geglu320_kernel(const imd_ff_params
     step(FF_NCH, F_{}, T_{}, T_{});
     step(FF_NCH + 1, F_{}, F_{}, T_{});
 
-    // ---- epilogue: + b2 + residual (the un-normalised input rows, re-read in accumulator layout), 8-byte stores ----
+    // ---- epilogue: + b2 + residual (the un-normalised input rows, re-read in accumulator layout), 16-byte stores ----
     const float* b2s = reinterpret_cast<const float*>(smem + FF_OFF_B2);
     const uint32_t o_bytes = (uint32_t)(((size_t)(p.M - 1) * p.out_ld + FF_C) * 2);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, o_bytes, 0x00020000);
@@ -241,17 +241,27 @@ __global__ __launch_bounds__(512, 1) void ff_geglu320_kernel(const imd_ff_params
             const int n = hh * 160 + cb * 32 + 8 * q + 4 * hi;
             res[cb][q] = buf_load8(rs_x, m < p.M ? rbase + (uint32_t)(n * 2) : OOB);
         }
+    // (round 5) 16-byte stores: one v_permlane32_swap per packed register pair turns the accumulator layout's two 4-channel groups into 8
+    // consecutive channels per lane -- half as many store requests, 32 contiguous bytes per row (row_linear.hip: "WIDE stores")
 #pragma unroll
     for (int cb = 0; cb < 5; ++cb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = hh * 160 + cb * 32 + 8 * q + 4 * hi;
-            const float4 bb = *reinterpret_cast<const float4*>(b2s + n);
-            const float v0 = acc_out[cb][4 * q] + bb.x + E::lo(res[cb][q].x), v1 = acc_out[cb][4 * q + 1] + bb.y + E::hi(res[cb][q].x);
-            const float v2 = acc_out[cb][4 * q + 2] + bb.z + E::lo(res[cb][q].y), v3 = acc_out[cb][4 * q + 3] + bb.w + E::hi(res[cb][q].y);
-            typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
-            const v2u pk = {E::pack2(v0, v1), E::pack2(v2, v3)};
-            __builtin_amdgcn_raw_buffer_store_b64(pk, rs_o, (int)(m < p.M ? obase + (uint32_t)(n * 2) : OOB), 0, 0);
+        for (int t = 0; t < 2; ++t) {
+            uint32_t pk[2][2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * t + qq, n = hh * 160 + cb * 32 + 8 * q + 4 * hi;
+                const float4 bb = *reinterpret_cast<const float4*>(b2s + n);
+                const float v0 = acc_out[cb][4 * q] + bb.x + E::lo(res[cb][q].x), v1 = acc_out[cb][4 * q + 1] + bb.y + E::hi(res[cb][q].x);
+                const float v2 = acc_out[cb][4 * q + 2] + bb.z + E::lo(res[cb][q].y), v3 = acc_out[cb][4 * q + 3] + bb.w + E::hi(res[cb][q].y);
+                pk[qq][0] = E::pack2(v0, v1); pk[qq][1] = E::pack2(v2, v3);
+            }
+            const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
+            const v4u_t w = {r0[0], r1[0], r0[1], r1[1]};
+            const int n8 = hh * 160 + cb * 32 + 16 * t + 8 * hi;
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, (int)(m < p.M ? obase + (uint32_t)(n8 * 2) : OOB), 0, 0);
         }
 }
 

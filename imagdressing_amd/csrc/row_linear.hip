@@ -153,9 +153,17 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
         if (p.mode == OUT_HEADS) { const int bi = m / HWo, tok = m - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
         else obase = (uint32_t)m * (uint32_t)(p.out_ld * 2);
     }
+    // WIDE stores (round 5): the accumulator layout gives a lane 4 channels of a row, so an 8-byte store instruction puts 16 contiguous bytes
+    // into each of 32 rows -- fragments the L2 takes at its REQUEST rate (measured on the GEMM epilogues: 16-byte fragments drain at 2.5 TB/s, a
+    // plain fill writes at 6.2, profiles/r5d_write_bw_probe.jsonl).  One v_permlane32_swap per packed register pair turns two 4-channel groups
+    // into 8 consecutive channels per lane: half as many store requests, 32 contiguous bytes per row.  (Tuning knob 2 bit 10 = the 8-byte form.)
+    const bool wide = (p.flags & 1024) != 0;
     auto emit = [&](int c) {
         const float* bias_s = reinterpret_cast<const float*>(smem + RL_LDS);
         const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
+        typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
+        typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
+        v2u pk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = c * 64 + chh * 32 + 8 * j + 4 * hi;
@@ -166,12 +174,25 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
                 v0 += E::lo(rres[c & 1][j].x); v1 += E::hi(rres[c & 1][j].x);
                 v2 += E::lo(rres[c & 1][j].y); v3 += E::hi(rres[c & 1][j].y);
             }
-            uint32_t off;
-            if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; off = (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
-            else off = (uint32_t)(n * 2);
-            typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
-            const v2u pk = {E::pack2(v0, v1), E::pack2(v2, v3)};
-            __builtin_amdgcn_raw_buffer_store_b64(pk, rs_o, (int)(obase == OOB ? OOB : obase + off), 0, 0);
+            pk[j] = v2u{E::pack2(v0, v1), E::pack2(v2, v3)};
+        }
+        auto offset_of = [&](int n) -> uint32_t {
+            if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; return (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
+            return (uint32_t)(n * 2);
+        };
+        if (wide) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {      // groups j = 2 t (channels 16 t + 4 hi ..) and 2 t + 1 (16 t + 8 + 4 hi ..) -> channels 16 t + 8 hi + 0..7
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pk[2 * t][0], pk[2 * t + 1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pk[2 * t][1], pk[2 * t + 1][1], false, false);
+                const v4u_t w = {r0[0], r1[0], r0[1], r1[1]};
+                const uint32_t off = offset_of(c * 64 + chh * 32 + 16 * t + 8 * hi);
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, (int)(obase == OOB ? OOB : obase + off), 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_buffer_store_b64(pk[j], rs_o, (int)(obase == OOB ? OOB : obase + offset_of(c * 64 + chh * 32 + 8 * j + 4 * hi)), 0, 0);
         }
     };
 
@@ -279,7 +300,7 @@ int imd_launch_row_linear(const ConvGemmParams& p_in, int ln, float ln_eps, hipS
     p.x_bytes = (uint32_t)xb;
     p.w_bytes = (uint32_t)wb;
     p.split_k = 1;
-    p.flags = 0;
+    p.flags = (g_gemm_flags & 1024) ? 0 : 1024;        // bit 10 of the kernel's flags: wide (16-byte) stores of the direct epilogue
     const bool h = p.dtype == IMD_DTYPE_F16;
     if (ln) return h ? launch_rl_n<true, true>(p, ln_eps, s) : launch_rl_n<false, true>(p, ln_eps, s);
     return h ? launch_rl_n<true, false>(p, ln_eps, s) : launch_rl_n<false, false>(p, ln_eps, s);

@@ -146,7 +146,11 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
     const float* bias_s = reinterpret_cast<const float*>(smem + R6_OFF_BIAS);
     const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
     float own[8];                      // this wave's two quads of the previous chunk (its own partial sums)
-    auto emit = [&](int c) {           // chunk c: own partial + the partner's, bias, scale, residual, two 8-byte stores
+    const bool wide = (p.flags & 1024) != 0;      // 16-byte stores of 8 consecutive channels (row_linear.hip: "WIDE stores"); knob 2 bit 10 = the 8-byte form
+    auto emit = [&](int c) {           // chunk c: own partial + the partner's, bias, scale, residual, one 16-byte (or two 8-byte) stores
+        typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
+        typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
+        v2u pk[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float4 o = red[((c & 1) * 8 + (wave ^ 4)) * 128 + j * 64 + lane];
@@ -158,13 +162,21 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
                 v0 += E::lo(rres[c & 1][j].x); v1 += E::hi(rres[c & 1][j].x);
                 v2 += E::lo(rres[c & 1][j].y); v3 += E::hi(rres[c & 1][j].y);
             }
-            const int n = n0 + nl;
-            uint32_t off;
-            if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; off = (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
-            else off = (uint32_t)(n * 2);
-            typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
-            const v2u pk = {E::pack2(v0, v1), E::pack2(v2, v3)};
-            __builtin_amdgcn_raw_buffer_store_b64(pk, rs_o, (int)(obase == OOB ? OOB : obase + off), 0, 0);
+            pk[j] = v2u{E::pack2(v0, v1), E::pack2(v2, v3)};
+        }
+        auto offset_of = [&](int n) -> uint32_t {
+            if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; return (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
+            return (uint32_t)(n * 2);
+        };
+        if (wide) {                    // quads 2 kh (channels 16 kh + 4 hi ..) and 2 kh + 1 (16 kh + 8 + 4 hi ..) -> channels 16 kh + 8 hi + 0..7 of the chunk
+            const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+            const v4u_t w = {r0[0], r1[0], r0[1], r1[1]};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, (int)(obase == OOB ? OOB : obase + offset_of(n0 + 32 * c + 16 * kh + 8 * hi)), 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_buffer_store_b64(pk[j], rs_o, (int)(obase == OOB ? OOB : obase + offset_of(n0 + 32 * c + 8 * (2 * kh + j) + 4 * hi)), 0, 0);
         }
     };
 
@@ -237,7 +249,7 @@ int imd_launch_row_linear_k640(const ConvGemmParams& p_in, int ln, float ln_eps,
     p.x_bytes = (uint32_t)xb;
     p.w_bytes = (uint32_t)wb;
     p.split_k = 1;
-    p.flags = 0;
+    p.flags = (g_gemm_flags & 1024) ? 0 : 1024;        // bit 10: wide (16-byte) stores of the direct epilogue
     const bool h = p.dtype == IMD_DTYPE_F16;
     if (ln) return h ? launch_r6<true, true>(p, ln_eps, s) : launch_r6<false, true>(p, ln_eps, s);
     return h ? launch_r6<true, false>(p, ln_eps, s) : launch_r6<false, false>(p, ln_eps, s);

@@ -112,26 +112,46 @@ __global__ __launch_bounds__(512, 1) void row_qkv_kernel(const ConvGemmParams p,
         if (which < 2) {          // D[channel][token]: lane = token, quad j = channels 8 j + 4 hi .. + 3
             const bool ok = m < p.M;
             const uint32_t obase = (uint32_t)(((size_t)bi * p.hH * hd.L + (tok0 + col)) * hd.DP * 2);
+            // (round 5) 16-byte stores of 8 consecutive channels: one v_permlane32_swap per packed register pair (row_linear.hip: "WIDE stores");
+            // an 8-channel group never straddles a head (head dim 40 = 5 x 8)
+            typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = c * 64 + chh * 32 + 8 * j + 4 * hi;     // channel in [0, 960)
-                const int nc = n - which * RQ_K, h = nc / p.hD, dd = nc - h * p.hD;
-                const float4 bb = *reinterpret_cast<const float4*>(bs + n);
-                const v2u pk = {E::pack2((acc[4 * j] + bb.x) * hd.scale, (acc[4 * j + 1] + bb.y) * hd.scale),
-                                E::pack2((acc[4 * j + 2] + bb.z) * hd.scale, (acc[4 * j + 3] + bb.w) * hd.scale)};
-                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_o, (int)(ok ? obase + (uint32_t)((h * hd.L * hd.DP + dd) * 2) : OOB), 0, 0);
+            for (int t = 0; t < 2; ++t) {
+                uint32_t pk[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * t + jj, n = c * 64 + chh * 32 + 8 * j + 4 * hi;     // channel in [0, 960)
+                    const float4 bb = *reinterpret_cast<const float4*>(bs + n);
+                    pk[jj][0] = E::pack2((acc[4 * j] + bb.x) * hd.scale, (acc[4 * j + 1] + bb.y) * hd.scale);
+                    pk[jj][1] = E::pack2((acc[4 * j + 2] + bb.z) * hd.scale, (acc[4 * j + 3] + bb.w) * hd.scale);
+                }
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                const v4u_t w = {r0[0], r1[0], r0[1], r1[1]};
+                const int n8 = c * 64 + chh * 32 + 16 * t + 8 * hi;
+                const int nc = n8 - which * RQ_K, h = nc / p.hD, dd = nc - h * p.hD;
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, (int)(ok ? obase + (uint32_t)((h * hd.L * hd.DP + dd) * 2) : OOB), 0, 0);
             }
         } else {                  // swapped MFMA, D[token][channel]: lane = channel, quad j = tokens 8 j + 4 hi .. + 3
             const int n = c * 64 + chh * 32 + col;
             const int nc = n - 2 * RQ_K, h = nc / p.hD, dd = nc - h * p.hD;
             const float b = bs[n];
             const uint32_t obase = (uint32_t)((((size_t)bi * p.hH + h) * hd.DP + dd) * hd.L * 2);       // hd.L = padded row length
+            typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = 8 * j + 4 * hi;
-                const v2u pk = {E::pack2((acc[4 * j] + b) * hd.scale, (acc[4 * j + 1] + b) * hd.scale),
-                                E::pack2((acc[4 * j + 2] + b) * hd.scale, (acc[4 * j + 3] + b) * hd.scale)};
-                __builtin_amdgcn_raw_buffer_store_b64(pk, rs_o, (int)(m0 + rb * 32 + t < p.M ? obase + (uint32_t)((tok0 + t) * 2) : OOB), 0, 0);
+            for (int tt = 0; tt < 2; ++tt) {      // quads 2 tt, 2 tt + 1 -> 8 consecutive tokens 16 tt + 8 hi .. of this lane's channel: one 16-byte store
+                uint32_t pk[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * tt + jj;
+                    pk[jj][0] = E::pack2((acc[4 * j] + b) * hd.scale, (acc[4 * j + 1] + b) * hd.scale);
+                    pk[jj][1] = E::pack2((acc[4 * j + 2] + b) * hd.scale, (acc[4 * j + 3] + b) * hd.scale);
+                }
+                const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+                const v4u_t w = {r0[0], r1[0], r0[1], r1[1]};
+                const int t = 16 * tt + 8 * hi;
+                __builtin_amdgcn_raw_buffer_store_b128(w, rs_o, (int)(m0 + rb * 32 + t < p.M ? obase + (uint32_t)((tok0 + t) * 2) : OOB), 0, 0);
             }
         }
     };
