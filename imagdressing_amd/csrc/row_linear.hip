@@ -67,13 +67,22 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     // measured 9 us of the 21; HBM absorbs writes at only ~2.3 TB/s, so the 21 MB of output are the longest phase and
     // everything else should hide under them).  The residual of chunk c is requested while chunk c is multiplied and
     // consumed one chunk later, so its 21 MB ride under the output stream as well; the bias sits in LDS behind the ring.
-    uint2 rres[2][4];
+    uint4 rraw[2][2];                                            // residual of a chunk: per register-group pair t, (group 2 t | group 2 t + 1) or, wide, 8 consecutive channels
+    const bool wide = (p.flags & 1024) != 0;                     // 16-byte stores / residual loads (see emit)
     const bool has_res = DIRECT && !LN && p.res != nullptr;      // (LayerNorm + residual: staged epilogue)
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, 0x80000000u, 0x00020000);
-    const uint32_t roff = (uint32_t)m * (uint32_t)(p.res_ld * 2) + (uint32_t)((wave >> 2) * 64 + hi * 8);
-    auto load_res = [&](int c) {        // residual of chunk c in accumulator layout (lane = token, 4 consecutive channels per 8-byte load)
+    const uint32_t roff = (uint32_t)m * (uint32_t)(p.res_ld * 2) + (uint32_t)((wave >> 2) * 64);
+    auto load_res = [&](int c) {        // residual of chunk c: lane = token; 8 consecutive channels per 16-byte load (wide; put into the accumulator layout
+                                        // by emit), or 4 per 8-byte load in accumulator layout
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rres[c & 1][j] = buf_load8(rs_r, m < p.M ? roff + (uint32_t)(c * 128 + j * 16) : OOB);
+        for (int t = 0; t < 2; ++t) {
+            if (wide) rraw[c & 1][t] = buf_load16(rs_r, m < p.M ? roff + (uint32_t)(c * 128 + t * 32 + hi * 16) : OOB);
+            else {
+                const uint2 a = buf_load8(rs_r, m < p.M ? roff + (uint32_t)(c * 128 + (2 * t) * 16 + hi * 8) : OOB);
+                const uint2 b = buf_load8(rs_r, m < p.M ? roff + (uint32_t)(c * 128 + (2 * t + 1) * 16 + hi * 8) : OOB);
+                rraw[c & 1][t] = make_uint4(a.x, a.y, b.x, b.y);
+            }
+        }
     };
     float bias_v = 0.f;              // requested behind the activation rows; parked in LDS once they have arrived (below)
     if (DIRECT && tid < NC * RL_CH && p.bias) bias_v = p.bias[tid];
@@ -157,9 +166,21 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     // into each of 32 rows -- fragments the L2 takes at its REQUEST rate (measured on the GEMM epilogues: 16-byte fragments drain at 2.5 TB/s, a
     // plain fill writes at 6.2, profiles/r5d_write_bw_probe.jsonl).  One v_permlane32_swap per packed register pair turns two 4-channel groups
     // into 8 consecutive channels per lane: half as many store requests, 32 contiguous bytes per row.  (Tuning knob 2 bit 10 = the 8-byte form.)
-    const bool wide = (p.flags & 1024) != 0;
     auto emit = [&](int c) {
         const float* bias_s = reinterpret_cast<const float*>(smem + RL_LDS);
+        uint2 rres[4];                     // residual in accumulator layout: group j = channels 8 j + 4 hi .. + 3
+        if (has_res) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint4 r = rraw[c & 1][t];
+                if (wide) {                // lane hi = 0 holds channels 16 t + 0..7, hi = 1 holds 16 t + 8..15: swap hi = 0's upper half with hi = 1's lower half
+                    const auto sx = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
+                    const auto sy = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
+                    r = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                }
+                rres[2 * t] = make_uint2(r.x, r.y); rres[2 * t + 1] = make_uint2(r.z, r.w);
+            }
+        }
         const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
         typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
         typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
@@ -171,8 +192,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
             float v0 = (acc[c][4 * j] + bb.x) * osc, v1 = (acc[c][4 * j + 1] + bb.y) * osc;
             float v2 = (acc[c][4 * j + 2] + bb.z) * osc, v3 = (acc[c][4 * j + 3] + bb.w) * osc;
             if (has_res) {
-                v0 += E::lo(rres[c & 1][j].x); v1 += E::hi(rres[c & 1][j].x);
-                v2 += E::lo(rres[c & 1][j].y); v3 += E::hi(rres[c & 1][j].y);
+                v0 += E::lo(rres[j].x); v1 += E::hi(rres[j].x);
+                v2 += E::lo(rres[j].y); v3 += E::hi(rres[j].y);
             }
             pk[j] = v2u{E::pack2(v0, v1), E::pack2(v2, v3)};
         }

@@ -134,23 +134,34 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
     }
     const bool has_res = p.res != nullptr;
     const uint32_t roff = (uint32_t)m * (uint32_t)(p.res_ld * 2);
-    uint2 rres[2][2];
+    uint4 rraw[2];                     // residual of a chunk: (quad 2 kh | quad 2 kh + 1) in accumulator layout or, wide, 8 consecutive channels
+    const bool wide = (p.flags & 1024) != 0;      // 16-byte stores / residual loads of 8 consecutive channels (row_linear.hip: "WIDE stores"); knob 2 bit 10 = the 8-byte form
     auto load_res = [&](int c) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 32 * c + 8 * (2 * kh + j) + 4 * hi;
-            rres[c & 1][j] = buf_load8(rs_r, m < p.M ? roff + (uint32_t)(n * 2) : OOB);
+        if (wide) rraw[c & 1] = buf_load16(rs_r, m < p.M ? roff + (uint32_t)((n0 + 32 * c + 16 * kh + 8 * hi) * 2) : OOB);
+        else {
+            const uint2 a = buf_load8(rs_r, m < p.M ? roff + (uint32_t)((n0 + 32 * c + 8 * (2 * kh) + 4 * hi) * 2) : OOB);
+            const uint2 b = buf_load8(rs_r, m < p.M ? roff + (uint32_t)((n0 + 32 * c + 8 * (2 * kh + 1) + 4 * hi) * 2) : OOB);
+            rraw[c & 1] = make_uint4(a.x, a.y, b.x, b.y);
         }
     };
     float4* red = reinterpret_cast<float4*>(smem + R6_OFF_RED);          // [2][8 waves][2 quads][64 lanes]
     const float* bias_s = reinterpret_cast<const float*>(smem + R6_OFF_BIAS);
     const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
     float own[8];                      // this wave's two quads of the previous chunk (its own partial sums)
-    const bool wide = (p.flags & 1024) != 0;      // 16-byte stores of 8 consecutive channels (row_linear.hip: "WIDE stores"); knob 2 bit 10 = the 8-byte form
     auto emit = [&](int c) {           // chunk c: own partial + the partner's, bias, scale, residual, one 16-byte (or two 8-byte) stores
         typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
         typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
         v2u pk[2];
+        uint2 rres[2];                 // residual in accumulator layout
+        if (has_res) {
+            uint4 r = rraw[c & 1];
+            if (wide) {
+                const auto sx = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
+                r = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            }
+            rres[0] = make_uint2(r.x, r.y); rres[1] = make_uint2(r.z, r.w);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float4 o = red[((c & 1) * 8 + (wave ^ 4)) * 128 + j * 64 + lane];
@@ -159,8 +170,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
             float v0 = (own[4 * j] + o.x + bb.x) * osc, v1 = (own[4 * j + 1] + o.y + bb.y) * osc;
             float v2 = (own[4 * j + 2] + o.z + bb.z) * osc, v3 = (own[4 * j + 3] + o.w + bb.w) * osc;
             if (has_res) {
-                v0 += E::lo(rres[c & 1][j].x); v1 += E::hi(rres[c & 1][j].x);
-                v2 += E::lo(rres[c & 1][j].y); v3 += E::hi(rres[c & 1][j].y);
+                v0 += E::lo(rres[j].x); v1 += E::hi(rres[j].x);
+                v2 += E::lo(rres[j].y); v3 += E::hi(rres[j].y);
             }
             pk[j] = v2u{E::pack2(v0, v1), E::pack2(v2, v3)};
         }
