@@ -205,7 +205,8 @@ def kernel_level_baseline(device, dtype, cores):
     (oracle/processors.py::hybrid_self_attention, pinned on the reference source; fp32 torch on `cores` threads, 2 warm-up + 5 timed calls)
     beside the HIP processor (three launches: q/k/v projection, fused two-softmax attention, out-projection + bias; HIP events over 20
     calls after 3 warm-up, garment K / V cached as in the loop) at the four (C, N = M) shapes of the 512x512 UNet, batch 1, garment
-    branch on.  FLOPs per call: 8 N C^2 + 4 N^2 C + 4 N M C (the garment K / V projection is once per garment: excluded on both sides)."""
+    branch on.  FLOPs per call: 8 N C^2 + 4 N^2 C + 4 N M C (the garment K / V projection is once per garment: excluded on both sides).
+    The HIP figure is what a CALLER of the processor sees: below ~75 us it is the Python plugin surface + three launches, not the kernels."""
     from imagdressing_amd.adapter import attention_processor as AP
     from imagdressing_amd.unet import Attention
     from oracle import processors as OP
@@ -246,7 +247,8 @@ def kernel_level_baseline(device, dtype, cores):
                      "hip_us": round(hip_us, 2), "hip_tflops": round(fl / hip_us / 1e6, 1), "speedup": round(cpu_ms * 1e3 / hip_us, 1),
                      "max_abs_diff_hip_vs_cpu": round(err, 5)})
     return {"what": "hybrid attention processor alone (RefSAttnProcessor2_0, garment branch on, batch 1): fp32 CPU port of the reference processor vs "
-                    f"the HIP processor ({str(dtype).replace('torch.', '')}), per UNet level of the 512x512 geometry", "cores": cores, "shapes": rows}
+                    f"the HIP processor ({str(dtype).replace('torch.', '')}) called through the plugin surface (host-bound below ~75 us per call), per UNet level of the 512x512 geometry",
+            "cores": cores, "shapes": rows}
 
 
 def run_other_config(cid, what, device, dtype, args, runs=3):
