@@ -413,7 +413,32 @@ __global__ __launch_bounds__(256, CKD == 32 ? 3 : 2) void conv3x3_patch_kernel(c
     const int st_n = n0 + (tid % CPR) * 8;
     const int st_split = min(8, (st_n / cpg + 1) * cpg - st_n);       // channels [0, split) of the chunk -> its first group
     float st[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+    // (round 5) The residual of ALL eight chunks this thread emits is fetched before its first store.  A load issued between two stores makes
+    // the wait for the load a wait for the store (vmcnt counts in order): the loop form load -> compute -> store paid a store round trip per chunk
+    // (DESIGN section 6, round-5 findings).  CHUNKS == 4 * 256: every thread owns chunks tid + 256 i of both 64-row passes.
+    static_assert(CHUNKS == 4 * 256, "the epilogue's residual prefetch assumes four chunks per thread and pass");
+    const bool pre_res = slab == nullptr && p.res != nullptr;
+    uint4 rpre[2][4];
+    auto chunk_geom = [&](int wr, int i, int& m, int& n) -> bool {
+        const int ch = tid + 256 * i;
+        const int row = ch / CPR, cc = (ch - row * CPR) * 8;
+        const int q = wr * EROWS + row;
+        const int oy = y0 + q / TW, ox = x0 + q % TW;
+        m = (b * H + oy) * W + ox;
+        n = n0 + cc;
+        return n < p.N && oy < H && ox < W;
+    };
+    if (pre_res) {
+#pragma unroll
+        for (int wr = 0; wr < 2; ++wr)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int m, n;
+                rpre[wr][i] = make_uint4(0, 0, 0, 0);
+                if (chunk_geom(wr, i, m, n) && n + 8 <= p.N) rpre[wr][i] = *reinterpret_cast<const uint4*>(p.res + (size_t)m * p.res_ld + n);
+            }
+    }
+#pragma unroll
     for (int wr = 0; wr < 2; ++wr) {
         if ((wave >> 1) == wr) {
 #pragma unroll
@@ -427,13 +452,12 @@ __global__ __launch_bounds__(256, CKD == 32 ? 3 : 2) void conv3x3_patch_kernel(c
                     }
         }
         __syncthreads();
-        for (int ch = tid; ch < CHUNKS; ch += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ch = tid + 256 * i;
             const int row = ch / CPR, cc = (ch - row * CPR) * 8;
-            const int q = wr * EROWS + row;
-            const int oy = y0 + q / TW, ox = x0 + q % TW;
-            const int m = (b * H + oy) * W + ox;
-            const int n = n0 + cc;
-            if (n >= p.N || oy >= H || ox >= W) continue;
+            int m, n;
+            if (!chunk_geom(wr, i, m, n)) continue;
             const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc);
             const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CLD + cc + 4);
             if (slab) {
@@ -441,7 +465,7 @@ __global__ __launch_bounds__(256, CKD == 32 ? 3 : 2) void conv3x3_patch_kernel(c
             } else {
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 const int nv = (n + 8 <= p.N) ? 8 : 4;
-                epilogue8<F16>(p, v, m, n, nv, HW, use_col_pre, col_pre0, col_pre1);
+                epilogue8<F16>(p, v, m, n, nv, HW, use_col_pre, col_pre0, col_pre1, pre_res && nv == 8, rpre[wr][i]);
                 if (want_stats) {               // v now holds the final values (bias / vector / residual / activation applied)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
