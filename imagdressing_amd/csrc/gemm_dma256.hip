@@ -1,21 +1,20 @@
-// 256-row LDS-DMA GEMM for the large plain linear layers -- the GEGLU / feed-forward-out projections of the 32x32 and 16x16 levels
+// 256-row LDS-DMA GEMM for the large plain linear layers -- the GEGLU / feed-forward-out / q-k-v projections of the 32x32 and 16x16 levels
 // (8192 x 5120 x 640, 2048 x 10240 x 1280, 8192 x 640 x 2560: ~10 % of the denoising step at 0.23-0.27 of the MFMA peak on the
-// 128 x 128 tiles of gemm_dma.hip).  Round 5.  What those shapes pay for on 128 x 128 tiles is not the multiplication (K = 640 is TEN
-// 64-deep steps) but what surrounds it once per tile: the launch ramp, the first operands' latency, and an epilogue through LDS that
-// nothing overlaps because every workgroup of a residency round reaches it at the same time.  This kernel removes the per-tile costs
-// instead of tuning the steps:
-//   * 256 x BN x 64 tiles (BN = 128: 48 KB per stage, THREE stages = 144 KB; BN = 256: 64 KB per stage, two stages), 8 waves
-//     (4 along M x 2 along N, wave tile 64 x BN/2), both operands global -> LDS by DMA in whole 128-byte rows (piece c of row r at
-//     c ^ ((r >> 1) & 7): conflict-free ds_read_b128, whole L2 lines), counted vmcnt;
-//   * PERSISTENT: one workgroup per CU walks a list of (tile, K slice) items, and the operand ring is ONE software pipeline across
-//     items -- while the last steps of item i are multiplied the first stages of item i + 1 are already landing, so an item's first
-//     operands cost no wait and the ramp is paid once per launch;
-//   * WAVE SPECIALISATION: two producer waves issue all LDS-DMA pieces, eight consumer waves multiply and store (see the kernel);
+// 128 x 128 tiles of gemm_dma.hip).  Round 5; tile configs 30 (persistent) / 31 (one item per workgroup).  DESIGN.md section 2.2e has the
+// ablation history that shaped it.  What those shapes pay for on 128 x 128 tiles is not the multiplication (K = 640 is TEN 64-deep steps) but
+// what surrounds it once per tile -- the launch ramp, the first operands' latency, the output stream -- so this kernel is built around those:
+//   * 256 x 128 x 64 tiles, THREE 48 KB stages (144 KB), both operands global -> LDS by DMA in whole 128-byte rows (piece c of row r at
+//     c ^ ((r >> 1) & 7): conflict-free ds_read_b128, whole L2 lines);
+//   * WAVE SPECIALISATION: four producer waves issue every LDS-DMA piece and are the only waves that wait on them; eight consumer waves
+//     (4 along M x 2 along N, 64 x 64 each) read fragments, multiply and store.  One workgroup barrier per step is the whole handshake;
+//   * PERSISTENT: one 12-wave workgroup per CU walks a list of (tile, K slice) items, and the producers' ring is ONE software pipeline
+//     across items -- while the last steps of item i are multiplied the first stages of item i + 1 are already landing;
 //   * the epilogue runs FROM REGISTERS: one v_permlane32_swap per accumulator register pair turns the 32x32 MFMA layout (4 channels per
-//     lane and register group) into 8 consecutive channels per lane, which go straight through epilogue8 (bias / residual / GEGLU /
-//     head-split layouts / fp32 slabs of K slices): no LDS staging, no barrier, and the ring keeps filling underneath it.
-// Same arithmetic as the tiled kernels (fp32 accumulation over K in 16-element MFMA steps, ascending), same reference layers
-// (diffusers-0.24 BasicTransformerBlock feed-forward: GEGLU proj + out linear).
+//     lane and register group) into 8 consecutive channels per lane -> epilogue8 (bias / residual / GEGLU / head-split layouts / fp32 slabs
+//     of K slices), every load of an item ahead of its first store; row-major 16-bit outputs leave through a wave-private 2 KB LDS
+//     transpose so that 4 lanes store 64 contiguous bytes of a row (16-byte fragments drain at the L2's request rate: 2.5 vs 6.2 TB/s).
+// Same arithmetic as the tiled kernels (fp32 accumulation over K in 16-element MFMA steps, ascending; bit-identical to tile config 25 without
+// K slices), same reference layers (diffusers-0.24 BasicTransformerBlock feed-forward: GEGLU proj + out linear).
 #include "gemm_common.h"
 #include "lds_dma.h"
 
@@ -51,8 +50,7 @@ __device__ __forceinline__ void g2_decode(const ConvGemmParams& p, unsigned w, u
     o.nk = min(nk_total, o.kt0 + per) - o.kt0;
 }
 
-// Wave specialisation: NPROD producer waves issue every LDS-DMA piece and are the only waves that wait on them; the eight consumer waves
-// multiply and store.  vmcnt is PER WAVE and counts loads and stores alike: a consumer that issued the DMA itself would have to drain its own
+// Why wave specialisation: vmcnt is PER WAVE and counts loads and stores alike -- a consumer that issued the DMA itself would have to drain its own
 // epilogue stores (84 MB per launch at the GEGLU shape: 27-34 us, the HBM write rate) before it could trust a counted wait on the next stage --
 // measured with the epilogue removed (profiles/r5b_gemm256_bench.jsonl: 97 -> 63 us).  With the roles split the stores of item i drain while
 // item i + 1 is multiplied, and a step's handshake is one workgroup barrier: the producers reach it after their counted wait (stage g + 1 has
