@@ -11,6 +11,7 @@ ap.add_argument("--cfgs", default="17,25,30,31")
 ap.add_argument("--ablate", action="store_true")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--only", type=int, default=-1, help="index of the one shape to run (PMC passes)")
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 lib = ops.L.load()
@@ -30,7 +31,8 @@ def timed(fn, iters):
 SHAPES = ((8192, 5120, 640, ops.ACT_GEGLU, False, 1), (2048, 10240, 1280, ops.ACT_GEGLU, False, 1), (8192, 640, 2560, ops.ACT_NONE, True, 1),
           (8192, 640, 2560, ops.ACT_NONE, True, 2), (2048, 1280, 5120, ops.ACT_NONE, True, 3), (8192, 1920, 640, ops.ACT_NONE, False, 1),
           (2048, 3840, 1280, ops.ACT_NONE, False, 1), (8192, 5120, 640, ops.ACT_NONE, False, 1))
-for M, N, K, act, res, split in SHAPES:
+for si, (M, N, K, act, res, split) in enumerate(SHAPES):
+    if a.only >= 0 and si != a.only: continue
     xs = [torch.randn(M, K, device="cuda").to(dt) for _ in range(3)]
     w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(dt); b = torch.randn(N, device="cuda")
     r = torch.randn(M, N, device="cuda").to(dt) if res else None
