@@ -144,7 +144,10 @@ def cpu_baseline(args):
     """Reference-semantics CPU port (oracle/: reference processors' math + restated diffusers UNet, fp32
     torch) timed on this host: `cpu-baseline-steps` DDIM steps at batch 1 = 2 B=1 UNet forwards each
     (IMAGDressing_v1_pipeline.py:499-518), extrapolated linearly to 50 steps (the one-off garment pass is
-    < 2 % of a run and is left out of the sample, which makes the CPU number slightly optimistic)."""
+    < 2 % of a run and is left out of the sample, which makes the CPU number slightly optimistic).
+    Attention products go through ``F.scaled_dot_product_attention`` exactly as the reference's processors call it
+    (adapter/attention_processor.py:589,607; ``oracle.processors.reference_sdpa_dispatch``) -- the oracle's explicit
+    [B, 8, N, N] softmax is 5-10x slower on a CPU and would understate the reference (round-5 review)."""
     from imagdressing_amd import unet as E
     from oracle import processors as OP
     from oracle import sd15
@@ -157,7 +160,7 @@ def cpu_baseline(args):
     cores = max(1, min(avail, 16))     # more torch threads than ~16 only adds contention at batch 1
     torch.set_num_threads(cores)
     lat_h, lat_w = (args.height or args.res) // 8, (args.width or args.res) // 8
-    with torch.no_grad():
+    with torch.no_grad(), OP.reference_sdpa_dispatch():
         u = sd15.UNet2DConditionModel()       # default-initialised fp32 weights (values do not affect timing)
         names = list(u.attn_processors.keys())
         boc = sd15.SD15["block_out_channels"]
@@ -179,6 +182,9 @@ def cpu_baseline(args):
         sch = DDIMOracle(); ts = sch.set_timesteps(args.ddim_steps)
         z = torch.randn(1, 4, lat_h, lat_w); pe = torch.randn(1, 77, 768) * 0.5; ne = torch.randn(1, 77, 768) * 0.5
         per_step, note = [], ""
+        t0 = time.time()
+        u(z, ts[0], ne)        # one untimed forward: first-touch of the 3.4 GB of fp32 weights and the allocator's arenas is not the path's cost
+        warm_s = time.time() - t0
         for i in range(args.cpu_baseline_steps):
             t = ts[i]
             t0 = time.time()
@@ -195,14 +201,16 @@ def cpu_baseline(args):
             per_step.append(t_c + t_u)
         dt = sum(per_step) / len(per_step)
     return dict(value=1.0 / (dt * args.ddim_steps), unit="images/s", cores=cores, kind="port",
+                attention="F.scaled_dot_product_attention, as the reference (adapter/attention_processor.py:589,607)",
                 sample=f"{len(per_step)} of {args.ddim_steps} DDIM steps at batch 1 (reference loop semantics: cond + uncond fp32 UNet "
                        f"forward per step, {dt:.2f} s/step mean of {[round(t, 2) for t in per_step]}, torch {torch.__version__} on {cores} threads), "
-                       f"extrapolated x{args.ddim_steps}{note}")
+                       f"extrapolated x{args.ddim_steps}{note}; one untimed warm-up forward first ({warm_s:.1f} s)")
 
 
 def kernel_level_baseline(device, dtype, cores):
     """BASELINE.md section 4.1 / SURVEY 8(d) CPU-baseline plan (i): the hybrid processor ALONE -- ``RefSAttnProcessor2_0`` semantics
-    (oracle/processors.py::hybrid_self_attention, pinned on the reference source; fp32 torch on `cores` threads, 2 warm-up + 5 timed calls)
+    (oracle/processors.py::hybrid_self_attention, pinned on the reference source, with its two attention products through
+    F.scaled_dot_product_attention like the reference's :589,607; fp32 torch on `cores` threads, 2 warm-up + 5 timed calls)
     beside the HIP processor (three launches: q/k/v projection, fused two-softmax attention, out-projection + bias; HIP events over 20
     calls after 3 warm-up, garment K / V cached as in the loop) at the four (C, N = M) shapes of the 512x512 UNet, batch 1, garment
     branch on.  FLOPs per call: 8 N C^2 + 4 N^2 C + 4 N M C (the garment K / V projection is once per garment: excluded on both sides).
@@ -220,14 +228,15 @@ def kernel_level_baseline(device, dtype, cores):
         x, ref = torch.randn(1, N, C, generator=g), torch.randn(1, M, C, generator=g)
         fl = 8.0 * N * C * C + 4.0 * N * N * C + 4.0 * N * M * C
         with torch.no_grad():
-            def cpu_call():
+            def cpu_call():      # (under reference_sdpa_dispatch below: SDPA as the reference's processor calls it)
                 return OP.hybrid_self_attention(x, w["wq"], w["wk"], w["wv"], w["wo"], bo, 8, ref=ref, wk_ref=w["wkr"], wv_ref=w["wvr"], scale=1.0)
-            for _ in range(2):
-                cpu_call()
-            t0 = time.perf_counter()
-            for _ in range(5):
-                cpu_out = cpu_call()
-            cpu_ms = (time.perf_counter() - t0) / 5 * 1e3
+            with OP.reference_sdpa_dispatch():
+                for _ in range(2):
+                    cpu_call()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    cpu_out = cpu_call()
+                cpu_ms = (time.perf_counter() - t0) / 5 * 1e3
             sd = {"a.to_q.weight": w["wq"], "a.to_k.weight": w["wk"], "a.to_v.weight": w["wv"], "a.to_out.0.weight": w["wo"], "a.to_out.0.bias": bo}
             attn = Attention(sd, "a", 8, str(device), dtype)
             proc = AP.RefSAttnProcessor2_0("blk.attn1.processor", C)
@@ -246,7 +255,7 @@ def kernel_level_baseline(device, dtype, cores):
         rows.append({"C": C, "N": N, "M": M, "gflop": round(fl / 1e9, 3), "cpu_ms": round(cpu_ms, 3), "cpu_gflops": round(fl / cpu_ms / 1e6, 1),
                      "hip_us": round(hip_us, 2), "hip_tflops": round(fl / hip_us / 1e6, 1), "speedup": round(cpu_ms * 1e3 / hip_us, 1),
                      "max_abs_diff_hip_vs_cpu": round(err, 5)})
-    return {"what": "hybrid attention processor alone (RefSAttnProcessor2_0, garment branch on, batch 1): fp32 CPU port of the reference processor vs "
+    return {"what": "hybrid attention processor alone (RefSAttnProcessor2_0, garment branch on, batch 1): fp32 CPU port of the reference processor (SDPA, as the reference) vs "
                     f"the HIP processor ({str(dtype).replace('torch.', '')}) called through the plugin surface (host-bound below ~75 us per call), per UNet level of the 512x512 geometry",
             "cores": cores, "shapes": rows}
 
