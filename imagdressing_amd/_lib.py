@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IMD_LIB_PATH") or os.path.join(_HERE, "libimagdressing_hip.so")     # override: A/B of two builds
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 u16p = C.POINTER(C.c_uint16)
 f32p = C.POINTER(C.c_float)

@@ -469,9 +469,17 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
     // tuning of this call: the caller's (IMD_TUNING_PER_CALL in flags on entry: bits 0..7 head-dim-40 variant, bit 8 plain work order) or the
     // process-wide knobs 0 / 1
-    const bool per_call = (p_in.flags & IMD_TUNING_PER_CALL) != 0;
+    const unsigned tag = (unsigned)p_in.flags & IMD_TUNING_TAG_MASK;
+    if (tag != 0 && tag != (unsigned)IMD_TUNING_PER_CALL)
+        return imd_set_error("attention: flags = 0x%x on entry is neither 0 nor IMD_TUNING_PER_CALL | bits (an uninitialised parameter block?)", (unsigned)p_in.flags);
+    const bool per_call = tag == (unsigned)IMD_TUNING_PER_CALL;
     const int qw40 = (per_call && (p_in.flags & 255)) ? (p_in.flags & 255) : g_attn_qw40;
-    if (qw40 < 1 || qw40 > 54) return imd_set_error("attention: per-call head-dim-40 variant %d out of range", qw40);
+#ifdef IMD_ABLATIONS
+    constexpr int QW40_MAX = 54;
+#else
+    constexpr int QW40_MAX = 13;            // (the range imd_set_tuning(0, .) accepts in this build)
+#endif
+    if (qw40 < 1 || qw40 > QW40_MAX) return imd_set_error("attention: per-call head-dim-40 variant %d out of range 1..%d", qw40, QW40_MAX);
     p.flags = (per_call ? !((p_in.flags >> 8) & 1) : g_attn_xcd != 0) ? 0 : 1;
     if (p.B <= 0 || p.H <= 0 || p.N <= 0 || p.L1 <= 0) return imd_set_error("attention: empty problem B=%d H=%d N=%d L1=%d", p.B, p.H, p.N, p.L1);
     if (p.L1P % 64 || p.L1P < p.L1) return imd_set_error("attention: L1P (%d) must be a multiple of 64 and >= L1 (%d)", p.L1P, p.L1);

@@ -101,7 +101,12 @@ int imd_set_tuning(int knob, int value) {
 #endif
             g_attn_qw40 = value; return 0;
         case 1: g_attn_xcd = value ? 1 : 0; return 0;
-        case 2: g_gemm_flags = value & 2047; return 0;   // (bit 8: row_linear staged epilogue, bit 9: halo-patch conv staged through registers, bit 10: row kernels store 8 bytes per lane; A/B only)
+        case 2:                                          // (bit 8: row_linear staged epilogue, bit 9: halo-patch conv staged through registers, bit 10: row kernels store 8 bytes per lane; A/B only)
+#ifndef IMD_ABLATIONS
+            IMD_REQUIRE((value & 224) == 0, "set_tuning: bits 5..7 of knob 2 are the timing ablations of gemm_dma256.hip (WRONG results); they exist only in -DIMD_ABLATIONS builds");
+#endif
+            IMD_REQUIRE((value & ~2047) == 0, "set_tuning: knob 2 has bits 0..10 only (got %d)", value);
+            g_gemm_flags = value; return 0;
         default: return imd_set_error("set_tuning: unknown knob %d", knob);
     }
 }

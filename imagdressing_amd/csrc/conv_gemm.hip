@@ -542,7 +542,10 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     if (cfg < 0) cfg = imd_conv_gemm_choose_cfg(p.M, p.N);
     if (p.split_k < 1) p.split_k = 1;
     // tuning bits of this call: the caller's (IMD_TUNING_PER_CALL in flags on entry) or the process-wide knob 2
-    const int gf = (p_in.flags & IMD_TUNING_PER_CALL) ? ((p_in.flags & 31) | (g_gemm_flags & ~31)) : g_gemm_flags;
+    const unsigned tag = (unsigned)p_in.flags & IMD_TUNING_TAG_MASK;
+    if (tag != 0 && tag != (unsigned)IMD_TUNING_PER_CALL)
+        return imd_set_error("conv_gemm: flags = 0x%x on entry is neither 0 nor IMD_TUNING_PER_CALL | bits (an uninitialised parameter block?)", (unsigned)p_in.flags);
+    const int gf = (tag == (unsigned)IMD_TUNING_PER_CALL) ? ((p_in.flags & 31) | (g_gemm_flags & ~31)) : g_gemm_flags;
     {
         const int bk = (cfg == 4) ? 32 : 64;
         p.flags = 0;
@@ -557,7 +560,9 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         p.flags |= imd_gemm_pick_order(p, (p.N + bn - 1) / bn);
         p.flags |= gf & 16;
     }
-    p.flags |= gf & 224;       // bits 5..7: timing ablations of gemm_dma256.hip (A/B only; WRONG results when set)
+#ifdef IMD_ABLATIONS
+    p.flags |= gf & 224;       // bits 5..7: timing ablations of gemm_dma256.hip (A/B only; WRONG results when set; imd_set_tuning refuses them otherwise)
+#endif
     if (p.split_k <= 1) p.splitk_counters = nullptr;
     // GroupNorm statistics of the output (ABI v6+): the halo-patch kernels' un-split epilogues (tile configs 5 / 22 / 23 / 29) and the finish
     // launch of any K-sliced problem produce them (imd_conv_gemm_stats_parts_of); every other request is an

@@ -86,10 +86,15 @@ __global__ __launch_bounds__((BM / 32) * 64 + (BM / 64) * 64, 3) void gemm_dma25
     const int nk_total = p.K / G2_BK;
     const int per = (nk_total + p.split_k - 1) / p.split_k;
     const int HWo = p.Hout * p.Wout;
-    // timing ablations with WRONG results (tuning knob 2 bits 5..7, tools/gemm256_bench.py): what is a launch made of
+    // timing ablations with WRONG results (tuning knob 2 bits 5..7, tools/gemm256_bench.py): what is a launch made of.  They exist in
+    // -DIMD_ABLATIONS builds only (like the attention kernel's): the product library neither compiles them nor lets knob 2 carry the bits
+#ifdef IMD_ABLATIONS
     const bool abl_noepi = (p.flags & 32) != 0;      // no epilogue
     const bool abl_nowait = (p.flags & 64) != 0;     // no DMA wait, no barrier in the steps: issue + fragment reads + MFMAs only
     const bool abl_nomfma = (p.flags & 128) != 0;    // no fragment reads / MFMAs: staging, synchronisation and the epilogue
+#else
+    constexpr bool abl_noepi = false, abl_nowait = false, abl_nomfma = false;
+#endif
     if (blockIdx.x >= items) return;                 // (uniform per workgroup)
 
     if (producer) {
@@ -338,26 +343,30 @@ __global__ __launch_bounds__((BM / 32) * 64 + (BM / 64) * 64, 3) void gemm_dma25
 
 template <int BM, int BN, int NST, bool PRE, bool RES>
 int launch_dma256_v(const ConvGemmParams& p, bool persistent, hipStream_t s, const char* what) {
-    static bool attr_set[2] = {false, false};
-    static int n_cu = 0;
+    // per DEVICE (a process may drive several GPUs): the 160 KB dynamic-LDS attribute is per device and the persistent grid is sized from
+    // the current device's CU count
+    constexpr int MAXDEV = 16;
+    static bool attr_set[MAXDEV][2] = {};
+    static int n_cu_of[MAXDEV] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return imd_set_error("%s: cannot identify the current device", what);
     constexpr int LDS = NST * (BM + BN) * G2_ROWB + (BM / 32) * 2048;      // ring + the consumer waves' 2 KB store-transpose areas
     constexpr int WG_PER_CU = BM == 256 ? 1 : 2;
     static_assert(LDS * WG_PER_CU <= 160 * 1024, "ring + transpose areas must fit the CU's LDS");
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = h ? gemm_dma256_kernel<true, BM, BN, NST, PRE, RES> : gemm_dma256_kernel<false, BM, BN, NST, PRE, RES>;
-    if (!attr_set[h]) {
+    if (!attr_set[dev][h]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
-        attr_set[h] = true;
+        attr_set[dev][h] = true;
     }
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return imd_set_error("%s: cannot query the device", what);
-        n_cu = prop.multiProcessorCount / 8 * 8;          // a multiple of 8: a block's items stay on its XCD's share of the tile order
-        if (n_cu < 8) n_cu = 8;
+    if (n_cu_of[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return imd_set_error("%s: cannot query the device", what);
+        n_cu_of[dev] = cus / 8 * 8 < 8 ? 8 : cus / 8 * 8;          // a multiple of 8: a block's items stay on its XCD's share of the tile order
     }
+    const int n_cu = n_cu_of[dev];
     const long items = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.split_k;
     const long slots = (long)n_cu * WG_PER_CU;
     const long grid = persistent ? (items < slots ? items : slots) : items;

@@ -198,7 +198,7 @@ int launch_rq(const ConvGemmParams& p, float eps, hipStream_t s) {
 bool imd_row_qkv_supported(const ConvGemmParams& p) {
     if (!(p.taps == 1 && p.K == RQ_K && p.Cin == RQ_K && p.N == RQ_N && p.mode == OUT_HEADS && p.hC == RQ_K && p.stride == 1 && !p.ups &&
           p.Hin == p.Hout && p.Win == p.Wout && p.split_k <= 1 && p.act == ACT_NONE && !p.out_f32 && p.rowvec == nullptr && p.res == nullptr &&
-          p.gn_a == nullptr && (p.x_pix_stride % 8) == 0 && p.out_scale == 1.0f && (p.hD % 4) == 0)) return false;
+          p.gn_a == nullptr && (p.x_pix_stride % 8) == 0 && p.out_scale == 1.0f && (p.hD % 8) == 0)) return false;      // (hD % 8: the 16-byte Q / K stores write 8 consecutive channels of ONE head)
     const int HWo = p.Hout * p.Wout;
     if (HWo % 128) return false;                                   // a 128-row workgroup must not straddle two images
     for (int i = 0; i < 3; ++i) {

@@ -154,45 +154,51 @@ _GEMM_TABLE = None
 # ---- per-call tuning (include/imagdressing_hip.h: IMD_TUNING_PER_CALL) ----------------------------------------------------------------
 # imd_set_tuning() is process-wide.  Inside ``with tuning_scope(...)`` every params block built by this module carries the scope's choice in
 # its `flags` field instead, so two pipelines of one process can run different settings (PipelineBase.set_tuning) and nothing global changes.
-TUNING_PER_CALL = 0x40000000
-_TUNING = None             # None | dict(attn_variant=int|None, attn_xcd=bool|None, gemm_flags=int|None)
+TUNING_PER_CALL = 0x5A000000   # 8-bit tag in bits 24..31 (ABI v9): anything else non-zero there is refused by the library
+ATTN_VARIANT_MAX = 13      # head-dim-40 variants a product build accepts (14..54 exist in -DIMD_ABLATIONS builds only)
+
+
+import contextvars
+
+# None | dict(attn_variant=int|None, attn_xcd=bool|None, gemm_flags=int|None).  A ContextVar, not a module global: two pipelines driven from
+# two threads (each on its own stream) keep their own scopes -- one thread's __exit__ cannot restore over the other's active scope.
+_TUNING = contextvars.ContextVar("imd_tuning_scope", default=None)
 
 
 class tuning_scope:
     """``with ops.tuning_scope(attn_variant=12, gemm_flags=3): ...`` -- head-dim-40 attention variant (knob 0), XCD-aware attention work
-    order (knob 1) and bits 0..4 of the GEMM tuning flags (knob 2) for the launches issued inside, per call.  Scopes nest; None = inherit."""
+    order (knob 1) and bits 0..4 of the GEMM tuning flags (knob 2) for the launches issued inside, per call.  Scopes nest; None = inherit.
+    The scope belongs to the calling thread / context.  It reaches ``ops.conv_gemm`` and ``ops.attention`` only: the fp8 attention, the
+    row-resident projections (``row_linear`` / ``row_qkv``) and the fused feed-forward have no per-call choice and ignore it."""
 
     def __init__(self, attn_variant=None, attn_xcd=None, gemm_flags=None):
         self.new = dict(attn_variant=attn_variant, attn_xcd=attn_xcd, gemm_flags=gemm_flags)
 
     def __enter__(self):
-        global _TUNING
-        self.prev = _TUNING
-        merged = dict(self.prev or {})
+        merged = dict(_TUNING.get() or {})
         merged.update({k: v for k, v in self.new.items() if v is not None})
-        _TUNING = merged if any(v is not None for v in merged.values()) else None
+        self.token = _TUNING.set(merged if any(v is not None for v in merged.values()) else None)
         return self
 
     def __exit__(self, *exc):
-        global _TUNING
-        _TUNING = self.prev
+        _TUNING.reset(self.token)
         return False
 
 
 def _gemm_call_flags() -> int:
-    t = _TUNING
+    t = _TUNING.get()
     if t is None or t.get("gemm_flags") is None:
         return 0
     return TUNING_PER_CALL | (int(t["gemm_flags"]) & 31)
 
 
 def _attn_call_flags() -> int:
-    t = _TUNING
+    t = _TUNING.get()
     if t is None or (t.get("attn_variant") is None and t.get("attn_xcd") is None):
         return 0
     v = int(t.get("attn_variant") or 0)
-    if not 0 <= v <= 54:
-        raise L.ImdError(f"tuning_scope: attention variant {v} out of range")
+    if not 0 <= v <= ATTN_VARIANT_MAX:
+        raise L.ImdError(f"tuning_scope: attention variant {v} out of range 0..{ATTN_VARIANT_MAX} (imd_set_tuning(0, .) of the product build)")
     if t.get("attn_xcd") is None:           # inherit the process-wide order
         xcd = bool(L.load().imd_get_tuning(1))
     else:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define IMD_ABI_VERSION 8
+#define IMD_ABI_VERSION 9
 
 enum { IMD_ACT_NONE = 0, IMD_ACT_SILU = 1, IMD_ACT_GEGLU = 2, IMD_ACT_GELU = 3, IMD_ACT_QUICK_GELU = 4 /* x * sigmoid(1.702 x): CLIP text MLP */ };
 enum { IMD_OUT_ROWMAJOR = 0, IMD_OUT_HEADS = 1 };
@@ -45,13 +45,17 @@ typedef struct imd_heads_dest {
     float scale;   /* multiplied in fp32 before rounding (softmax scale * log2 e folded into Q) */
 } imd_heads_dest;
 
-/* Per-call tuning (ABI v8, additive): `flags` of imd_conv_gemm_params / imd_attn_params is normally ignored on entry and filled in by the
- * library from the process-wide knobs of imd_set_tuning().  A caller that sets IMD_TUNING_PER_CALL in it chooses for THIS call only:
+/* Per-call tuning (ABI v8; tag widened in v9): `flags` of imd_conv_gemm_params / imd_attn_params is an INPUT.  0 (what a zero-initialised
+ * block carries) = use the process-wide knobs of imd_set_tuning().  A caller whose flags carry the 8-bit tag IMD_TUNING_PER_CALL in bits
+ * 24..31 -- (flags & IMD_TUNING_TAG_MASK) == IMD_TUNING_PER_CALL -- chooses for THIS call only:
  *   imd_conv_gemm:  bits 0..4 = bits 0..4 of tuning knob 2 (tap-inner K order, weight loads past L1, XCD-aware tile order, grouped order)
- *   imd_attention:  bits 0..7 = head-dim-40 kernel variant (tuning knob 0; 0 = the process-wide value), bit 8 = 1: plain work order
- *                   (tuning knob 1 = 0)
- * so two pipelines in one process can run different settings without touching global state (imagdressing_amd.ops.tuning_scope). */
-#define IMD_TUNING_PER_CALL 0x40000000
+ *   imd_attention:  bits 0..7 = head-dim-40 kernel variant (tuning knob 0; 0 = the process-wide value; validated against the same range
+ *                   as imd_set_tuning(0, .) of this build), bit 8 = 1: plain work order (tuning knob 1 = 0)
+ * so two pipelines in one process can run different settings without touching global state (imagdressing_amd.ops.tuning_scope).  Any
+ * other non-zero value in bits 24..31 is refused (v9): a block whose flags were left uninitialised does not silently select a tuning.
+ * The fp8 attention, row-resident projection and fused feed-forward entry points have no per-call choice and ignore the field. */
+#define IMD_TUNING_PER_CALL 0x5A000000
+#define IMD_TUNING_TAG_MASK 0xFF000000u
 
 typedef struct imd_conv_gemm_params {
     uint32_t struct_bytes; /* sizeof(imd_conv_gemm_params) in the caller's view (ABI v8); checked on entry */
@@ -262,7 +266,10 @@ int imd_attn_padded_dims(int D, int* dpk, int* dpv);
  * knob 1: XCD-aware work mapping of the attention grid (0|1);
  * knob 2: GEMM operand-fetch bits (bit0: tap-inner K order for 3x3 convs, bit1: weight loads bypass the L1,
  * bit2: XCD-aware tile order -- each XCD's L2 owns whole row tiles or whole channel tiles, whichever moves fewer bytes;
- * bit4: row tiles visited in groups of 8 inside an XCD's range). */
+ * bit4: row tiles visited in groups of 8 inside an XCD's range; A/B switches with identical results: bit8 row_linear's staged epilogue,
+ * bit9 the halo-patch conv staged through registers, bit10 8-byte stores in the row kernels.  Bits 5..7 are timing ablations of
+ * gemm_dma256.hip that compute WRONG results: compiled into, and accepted by, -DIMD_ABLATIONS builds only -- a normal build rejects
+ * them, and any bit above 10). */
 int imd_set_tuning(int knob, int value);
 /* current value of a knob (-1: unknown knob): lets a harness snapshot and restore the process-global settings around an A/B */
 int imd_get_tuning(int knob);

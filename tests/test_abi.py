@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 def test_binding_covers_header(lib):
     from imagdressing_amd import _lib
     assert sorted(_lib.SYMBOLS) == declared_functions()
-    assert lib.imd_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.imd_abi_version() == _lib.ABI_VERSION == 9
 
 
 def header_struct_fields(name):
@@ -95,7 +95,7 @@ def test_foreign_struct_size_is_refused(lib):
         assert p.struct_bytes == ctypes.sizeof(cls)
         p.struct_bytes = ctypes.sizeof(cls) - 8                 # what a binding of an older, shorter header would pass
         assert fn(ctypes.byref(p), *extra) != 0
-        assert b"parameter block is" in lib.imd_last_error() and b"ABI v8" in lib.imd_last_error()
+        assert b"parameter block is" in lib.imd_last_error() and b"ABI v9" in lib.imd_last_error()
         p.struct_bytes = 0                                      # a v7 caller: first word is the low half of a pointer or zero
         assert fn(ctypes.byref(p), *extra) != 0 and b"parameter block is" in lib.imd_last_error()
     q = _lib.ConvGemmParams()

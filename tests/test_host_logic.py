@@ -499,8 +499,34 @@ def test_tuning_scope_builds_per_call_flags():
                 assert ops._attn_call_flags() == ops.TUNING_PER_CALL | 12
                 assert ops._gemm_call_flags() == ops.TUNING_PER_CALL | 23
         assert ops._attn_call_flags() == 0
-    assert ops._TUNING is None
+    assert ops._TUNING.get() is None
     with pytest.raises(ops.L.ImdError):
         with ops.tuning_scope(attn_variant=99):
             ops._attn_call_flags()
-    assert ops._TUNING is None
+    with pytest.raises(ops.L.ImdError):          # 14..54 exist in -DIMD_ABLATIONS builds only: the same range imd_set_tuning(0, .) accepts
+        with ops.tuning_scope(attn_variant=14):
+            ops._attn_call_flags()
+    assert ops._TUNING.get() is None
+    # the tag is 8 bits wide (ABI v9) and the header's mask covers it
+    assert ops.TUNING_PER_CALL & 0x00FFFFFF == 0 and int(re.search(r"#define IMD_TUNING_TAG_MASK (0x[0-9a-fA-F]+)u", hdr).group(1), 16) == 0xFF000000
+
+
+def test_tuning_scope_is_per_thread():
+    """The scope lives in a ContextVar: a second thread (a second pipeline on its own stream) neither sees the first thread's scope nor
+    clobbers it when its own scope exits (round-5 advisor finding: a module global raced)."""
+    import threading
+    from imagdressing_amd import ops
+    seen, go, done = {}, threading.Event(), threading.Event()
+
+    def other():
+        seen["inherits"] = ops._gemm_call_flags()
+        with ops.tuning_scope(gemm_flags=1):
+            seen["own"] = ops._gemm_call_flags()
+            go.set(); done.wait(5)
+        seen["after"] = ops._gemm_call_flags()
+    with ops.tuning_scope(gemm_flags=3):
+        t = threading.Thread(target=other); t.start(); go.wait(5)
+        assert ops._gemm_call_flags() == ops.TUNING_PER_CALL | 3
+        done.set(); t.join()
+        assert ops._gemm_call_flags() == ops.TUNING_PER_CALL | 3          # the other thread's __exit__ did not restore over this scope
+    assert seen == {"inherits": 0, "own": ops.TUNING_PER_CALL | 1, "after": 0}
