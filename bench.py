@@ -387,7 +387,9 @@ def main():
             out = one_step()
         dec_events.clear()
         # roofline hook: bracket every level-0 hybrid-attention launch of the timed region with HIP events
-        hook = {"match": lambda B, H, N, D, L1, L2: D == 40 and N == N0 and L2 == N0, "events": []}
+        # (B == 2 * batch: the launch attn_flops_hybrid_level0 prices -- `batch` two-phase + `batch` one-phase rows.  The first hybrid block of a
+        # step runs the cond rows only with its first phase stored twice (round 6, imd_attn_params.out_dup): fewer FLOPs, not this launch.)
+        hook = {"match": lambda B, H, N, D, L1, L2: D == 40 and N == N0 and L2 == N0 and B == 2 * batch, "events": []}
         if hook_attention and not graph:
             ops.ATTN_EVENT_HOOK = hook
         barrier()

@@ -224,9 +224,12 @@ def _fp8_kv(kv, cache: bool):
 def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, self_attn: bool,
                      kv1=None, kv1_bdiv: int = 1, kv2=None, kv2_bdiv: int = 1, scale2: Optional[torch.Tensor] = None,
                      wo: torch.Tensor, bo: Optional[torch.Tensor], residual: Optional[torch.Tensor],
-                     q_ln: Optional[tuple] = None) -> torch.Tensor:
+                     q_ln: Optional[tuple] = None, pair_half: bool = False) -> torch.Tensor:
     """x [B, N, C] bf16 -> out-projected attention output [B, N, C] (+ residual).  ``q_ln`` = (W_q', b_q', eps): ``x`` is the
-    block's UN-normalised hidden state and LayerNorm runs inside the Q projection (cross-attention, C = 320 only)."""
+    block's UN-normalised hidden state and LayerNorm runs inside the Q projection (cross-attention, C = 320 only).
+    ``pair_half`` (self-attention with a garment key set only): ``x`` holds the B cond rows of a CFG batch whose uncond rows have
+    bit-identical hidden states; the result has 2B rows -- [0, B) the hybrid output, [B, 2B) the plain self-attention output of
+    the same rows (the attention launch stores its first phase twice, ``imd_attn_params.out_dup``) -- and ``residual`` has 2B rows."""
     B, N, Cc = x.shape
     D = Cc // heads
     dpk, dpv = ops.attn_padded_dims(D)
@@ -271,6 +274,12 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
         out = torch.empty(B, N, Cc, dtype=dt, device=dev)
         return ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True,
                              proj=(wo, bo, residual, out), **kw)
+    if pair_half:
+        o = torch.empty(2 * B, N, Cc, dtype=dt, device=dev)
+        ops.attention(q, kv1[0], kv1[1], o[:B], B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True,
+                      out_dup=o[B:], **kw)
+        res2 = None if residual is None else residual.view(2 * B * N, Cc)
+        return ops.linear(o.view(2 * B * N, Cc), wo, bo, res=res2).view(2 * B, N, Cc)
     ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True, **kw)
     res2 = None if residual is None else residual.view(B * N, Cc)
     return ops.linear(o.view(B * N, Cc), wo, bo, res=res2).view(B, N, Cc)
@@ -416,6 +425,9 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
     """Hybrid attention: frozen self-attention + trainable garment cross-attention
     (attention_processor.py:513-627)."""
     fused_layernorm = True      # engine-side opt-in: norm1 may run inside the q / k / v projection (see AttnProcessor2_0)
+    # engine-side opt-in (round 6): ``imd_pair_half=True`` -- hidden_states holds only the cond half of a CFG batch whose uncond half is
+    # bit-identical (first hybrid block), sa_batch_mask / imd_residual keep all 2B rows, the result has 2B rows (_fused_attention)
+    fused_pair_half = True
 
     def __init__(self, name, hidden_size, cross_attention_dim=None, scale=1.0):
         super().__init__()
@@ -426,7 +438,7 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, scale=1.0,
                  num_images_per_prompt=1, cond_hidden_states=None, sa_hidden_states=None, sa_batch_mask=None,
-                 imd_residual=None, imd_layernorm=None, **kwargs):
+                 imd_residual=None, imd_layernorm=None, imd_pair_half=False, **kwargs):
         if encoder_hidden_states is not None:
             raise NotImplementedError(f"{type(self).__name__} is a self-attention (attn1) processor")
         dt = _compute_dtype(attn, hidden_states, attention_mask)
@@ -445,9 +457,11 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
             ref = sa_hidden_states[self.name]
             kv2 = self._garment_kv(ref, attn.heads, x.device, x.dtype)
             bdiv2 = self._garment_bdiv(x.shape[0], ref)
-            s2 = self._branch_weights(x.shape[0], sa_batch_mask, x.device)
+            s2 = self._branch_weights(x.shape[0] * (2 if imd_pair_half else 1), sa_batch_mask, x.device)      # (pair_half: the kernel reads the cond rows' entries [0, B))
+        if imd_pair_half and (kv2 is None or imd_residual is None or shape4 is not None):
+            raise ValueError("imd_pair_half needs sa_hidden_states, the block residual and token-major hidden states (engine-internal)")
         out = _fused_attention(x, attn.heads, wq_or_qkv=wqkv, self_attn=True, kv2=kv2, kv2_bdiv=bdiv2,
-                               scale2=s2, wo=wo, bo=bo, residual=imd_residual, q_ln=q_ln)
+                               scale2=s2, wo=wo, bo=bo, residual=imd_residual, q_ln=q_ln, pair_half=bool(imd_pair_half))
         return self._finish(attn, out, imd_residual is not None, hidden_states, shape4, ln_fused=imd_layernorm is not None)
 
 
@@ -497,6 +511,7 @@ class _LoraRefSBase(nn.Module, _FusedBase, _RefMixin, _LoraFold):
         return w["qkv"], w["o"], _layer_weights(attn, "bo", dt, dev)
 
     __call__ = RefSAttnProcessor2_0.__call__
+    fused_pair_half = True      # (fused_layernorm stays off: the folded LayerNorm weights are built from attn.to_q/k/v, not from the LoRA-folded ones)
 
 
 class LoraRefSAttnProcessor2_0(_LoraRefSBase):

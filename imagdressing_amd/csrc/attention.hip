@@ -465,6 +465,8 @@ int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }
 
 int g_attn_xcd = 1;
 
+int imd_attention_dup_supported(int H, int N, int D) { return (D == 40 && N >= 512 && H > 0) ? 1 : 0; }
+
 int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
     // tuning of this call: the caller's (IMD_TUNING_PER_CALL in flags on entry: bits 0..7 head-dim-40 variant, bit 8 plain work order) or the
@@ -489,6 +491,12 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("attention: unknown dtype %d", p.dtype);
     if (p.causal && (p.k2 != nullptr || p.L1 != p.N)) return imd_set_error("attention: the causal mask needs a single key set with L1 == N");
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if (p.out_dup != nullptr) {         // duplicated first-phase output (ABI v9): the static-ring d = 40 kernel only
+        if (!imd_attention_dup_supported(p.H, p.N, p.D) || !p.k_pad_one || p.causal || p.proj_w != nullptr)
+            return imd_set_error("attention: out_dup needs head dim 40, N >= 512, k_pad_one, no causal mask and no fused out-projection (got D=%d N=%d k_pad_one=%d)", p.D, p.N, p.k_pad_one);
+        if (p.out_dup == p.out) return imd_set_error("attention: out_dup must not alias out");
+        return imd_launch_attention_d40(p, qw40 == 12 ? 12 : 13, s);      // (every other variant is an A/B form of these two)
+    }
     if (p.proj_w != nullptr) {          // fused out-projection: the d = 40 kernel (variant 10) only
         if (p.D != 40 || p.H * p.D != 320 || p.N < 512 || p.causal)
             return imd_set_error("attention: the fused out-projection needs head dim 40, 8 heads, N >= 512, no causal mask (got D=%d H=%d N=%d)", p.D, p.H, p.N);

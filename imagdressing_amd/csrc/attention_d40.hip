@@ -227,6 +227,13 @@ __device__ __attribute__((always_inline)) bool attn40_body(const AttnParams& p) 
     // MFMA + VALU + LDS + DMA mix costs in isolation; what is left above that is scalar / address bookkeeping like this.
     constexpr bool STAT = (VAR & 2097152) != 0;
     constexpr bool UNCHK = (VAR & 4194304) != 0;          // (with STAT) interior steps without the overflow test: experiment, see variant 13
+    // DUP (VAR & 8388608, round 6): the phase-0 (self-attention) result of every row is ALSO stored to p.out_dup -- the first hybrid block of
+    // the CFG batch: cond and uncond rows of an image have bit-identical Q / K / V there (same latent, same timestep, nothing text- or
+    // garment-dependent upstream), so the uncond row's whole output IS the cond row's first phase.  The launch runs the cond rows only
+    // (8 instead of 12 phase units at batch 4) and writes both: out = O1/l1 + s2 O2/l2 (cond), out_dup = O1/l1 (uncond) -- the same
+    // 16-bit rounding of O1/l1 the one-phase row stores and the two-phase row parks, hence bit-identical to the 2B-row launch.
+    constexpr bool DUP = (VAR & 8388608) != 0;
+    static_assert(!DUP || (STAT && !PROJ), "the duplicated phase-0 store lives in the static-ring kernel without the fused out-projection");
     // fp16 under UNCHK (round 5): the phase's reference maximum is the first block's maximum PLUS this bias, i.e. P = 2^(s - m_first - 4):
     // the first block's largest P is 2^-4 and fp16's 65504 is reached only by a score 20 base-2 units (a factor 10^6 in weight) above the
     // first 32 keys' maximum -- the end-of-phase denominator test (inf / NaN) then re-runs the workgroup checked.  The price is at the
@@ -832,6 +839,26 @@ __device__ __attribute__((always_inline)) bool attn40_body(const AttnParams& p) 
                     pk[2 * jj] = E::pack2(v[0], v[1]);
                     pk[2 * jj + 1] = E::pack2(v[2], v[3]);
                 }
+                if constexpr (DUP) {
+                    if (ph == 0) {                             // the paired (uncond) row's output: this row's self-attention result
+                        const int q = q0 + qb * 32 + col;
+                        if (q < p.N) {
+                            bf16_t* orow = p.out_dup + ((size_t)b * p.N + q) * p.out_ld + h * D;
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                *reinterpret_cast<uint2*>(orow + 8 * jj + 4 * hi) = make_uint2(pk[2 * jj], pk[2 * jj + 1]);
+                        }
+                        if (lane < 32) {
+#pragma unroll
+                            for (int hq = 0; hq < 2; ++hq) {
+                                const int qt = q0 + qb * 32 + 16 * hq + (lane & 15);
+                                if (qt < p.N)
+                                    *reinterpret_cast<uint2*>(p.out_dup + ((size_t)b * p.N + qt) * p.out_ld + h * D + 32 + 4 * (lane >> 4)) =
+                                        make_uint2(pk[8 + 2 * hq], pk[9 + 2 * hq]);
+                            }
+                        }
+                    }
+                }
                 if (ph == 0 && nph == 2) {
 #pragma unroll
                     for (int jj = 0; jj < 6; ++jj)
@@ -1047,11 +1074,15 @@ int imd_launch_attention_d40(const AttnParams& p, int variant, hipStream_t s) {
             }
             [[fallthrough]];
         case 13:            // round 4 (default): 12 without the per-step overflow test on interior steps; fp16 (round 5) with the reference maximum biased by 2^4 (FIRST_BIAS)
+            if (p.out_dup != nullptr)       // (validated by imd_launch_attention: k_pad_one, no fused out-projection)
+                return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 2097152 | 4194304 | 8388608>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 2097152 | 4194304 | 8388608>(p, s);
             if (p.proj_w == nullptr && p.k_pad_one)
                 return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 2097152 | 4194304>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 2097152 | 4194304>(p, s);
             [[fallthrough]];
         case 12:            // round 4: the LDS-DMA kernel with the main loop unrolled over the three ring slots -- compile-time LDS
         default:            // addresses, three-instruction staging pieces, no first / ragged-block test on interior steps
+            if (p.out_dup != nullptr)
+                return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 2097152 | 8388608>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 2097152 | 8388608>(p, s);
             if (p.proj_w == nullptr && p.k_pad_one)
                 return h ? launch_attn40<true, 8, 1 | 128 | 8192 | 2097152>(p, s) : launch_attn40<false, 8, 1 | 128 | 8192 | 2097152>(p, s);
             if (p.proj_w != nullptr) {      // fused out-projection (validated by imd_launch_attention)

@@ -454,6 +454,7 @@ int tile_dims(int cfg, int* bm, int* bn) {
         case 3: case 7: *bm = 64; *bn = 64; return 0;
         case 6: *bm = 64; *bn = 320; return 0;
         case 9: case 21: case 30: case 31: *bm = 256; *bn = 128; return 0;
+        case 32: *bm = 192; *bn = 128; return 0;
         case 22: *bm = 128; *bn = 160; return 0;
         case 23: *bm = 256; *bn = 160; return 0;
         case 24: *bm = 512; *bn = 64; return 0;
@@ -485,7 +486,7 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
     if (p.split_k > 1) {
-        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28) || (cfg >= 30 && cfg <= 31)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
+        if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28) || (cfg >= 30 && cfg <= 32)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
@@ -636,8 +637,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
             if (rc) return rc;
             return launch_splitk_finish(p, s, "conv_img split-K finish");
         }
-        case 30: case 31: {   // LDS-DMA tiles with producer / consumer waves and a register epilogue (gemm_dma256.hip): 30 = 256 x 128 x 64, three stages,
-                              // persistent over (tile, K slice) items; 31 = the same with one item per workgroup
+        case 30: case 31: case 32: {   // LDS-DMA tiles with producer / consumer waves and a register epilogue (gemm_dma256.hip): 30 = 256 x 128 x 64, three stages,
+                              // persistent over (tile, K slice) items; 31 = the same with one item per workgroup; 32 (round 6) = 192 x 128 x 64, persistent
             p.splitk_counters = nullptr;
             int rc = imd_launch_gemm_dma256(p, cfg - 30, s);
             if (rc || p.split_k <= 1) return rc;

@@ -61,11 +61,14 @@ __device__ __forceinline__ void g2_decode(const ConvGemmParams& p, unsigned w, u
 // workgroups per CU so that each one's epilogue falls into the other's multiplication -- was measured and is not dispatched: 108-124 us where the
 // 256-row form takes 65-72, profiles/r5f_gemm256_bench.jsonl: with two stages a producer can only issue stage g + 2 after the barrier that frees
 // stage g, one step of lead is less than the operands' latency.)
+// BM = 192 (round 6, tile config 32): six consumer + four producer waves.  For item counts that leave a third of the chip idle at 256 rows --
+// feed-forward out, 8192 x 640 x 2560: 32 x 5 = 160 tiles on 256 CUs -- 43 x 5 = 215 tiles of three quarters the work run in ONE round as well.
+template <int BM> struct G2Waves { static constexpr int NCW = BM / 32, NPROD = BM == 192 ? 4 : BM / 64; };
 template <bool F16, int BM, int BN, int NST, bool PRE, bool RES>
-__global__ __launch_bounds__((BM / 32) * 64 + (BM / 64) * 64, 3) void gemm_dma256_kernel       // (HIP: the second bound is WAVES PER SIMD -- twelve waves per CU either way)
+__global__ __launch_bounds__((G2Waves<BM>::NCW + G2Waves<BM>::NPROD) * 64, 3) void gemm_dma256_kernel       // (HIP: the second bound is WAVES PER SIMD -- twelve (ten) waves per CU either way)
 (const ConvGemmParams p) {
     using E = El<F16>;
-    constexpr int NCW = BM / 32, G2_NPROD = BM / 64;                 // consumer waves (BM / 64 along M x 2 along N), producer waves
+    constexpr int NCW = G2Waves<BM>::NCW, G2_NPROD = G2Waves<BM>::NPROD;   // consumer waves (BM / 64 along M x 2 along N), producer waves
     constexpr int G2_A = BM * G2_ROWB;                               // activation bytes per stage
     constexpr int APIECES = BM / 8;                                  // 1-KB pieces (8 rows x 128 B) of the activation tile
     constexpr int W_BYTES = BN * G2_ROWB;
@@ -210,17 +213,32 @@ __global__ __launch_bounds__((BM / 32) * 64 + (BM / 64) * 64, 3) void gemm_dma25
         // ---- the item's LAST step, with the epilogue's operands fetched in front of it ----
         float4 bn[NA][4];                             // bias in the ACCUMULATOR layout (4 channels per lane and register group): added to the finished sums, then dead
         uint4 rp[NA][2], rq[NA][2];                   // residual chunks of the lane's rows b = 0 (fetched here) and b = 1 (fetched when the epilogue starts, still ahead of every store)
+        auto load_bias = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {             // register group j: channels a * 32 + 8 j + 4 hi + 0..3
+                    const int nb = ci.n0 + wn0 + a * 32 + 8 * j + 4 * hi;
+                    bn[a][j] = (p.bias != nullptr && nb < p.N) ? *reinterpret_cast<const float4*>(p.bias + nb) : make_float4(0, 0, 0, 0);
+                }
+        };
+        float4 bias_l = make_float4(0, 0, 0, 0);
         if (pre_ok && !abl_noepi) {
+            // (round 6) with a residual the bias does NOT wait in 32 registers across the last step: beside the 16 + 16 residual registers and the
+            // 64 accumulators they pushed the kernel past its 168-register cap (14 VGPRs in scratch, two reloads inside the MFMA region).  Lanes
+            // 0..15 fetch the wave's 64 bias values here (one float4 each), park them in the wave's -- otherwise unused: residual tiles store
+            // directly -- 2 KB transpose area after the step, and every lane reads its four float4 per accumulator block back from LDS: four
+            // live registers instead of 32, no load behind a store.
+            if (!RES) load_bias();
+            else if (lane < 16) {
+                const int nb = ci.n0 + wn0 + 4 * lane;
+                if (p.bias != nullptr && nb < p.N) bias_l = *reinterpret_cast<const float4*>(p.bias + nb);
+            }
 #pragma unroll
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int n = ci.n0 + wn0 + a * 32 + 16 * t + 8 * hi;
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {      // register groups j = 2 t + jj: channels a * 32 + 8 j + 4 hi + 0..3
-                        const int nb = ci.n0 + wn0 + a * 32 + 8 * (2 * t + jj) + 4 * hi;
-                        bn[a][2 * t + jj] = (p.bias != nullptr && nb < p.N) ? *reinterpret_cast<const float4*>(p.bias + nb) : make_float4(0, 0, 0, 0);
-                    }
                     const int m = ci.m0 + wm0 + col;
                     rp[a][t] = make_uint4(0, 0, 0, 0);
                     if (RES && m < p.M && n + 8 <= p.N) rp[a][t] = *reinterpret_cast<const uint4*>(p.res + (size_t)m * p.res_ld + n);
@@ -231,29 +249,74 @@ __global__ __launch_bounds__((BM / 32) * 64 + (BM / 64) * 64, 3) void gemm_dma25
         if (!abl_noepi) {
             float* slab = (p.split_k > 1) ? p.splitk_ws + (size_t)ci.slice * p.M * p.N : nullptr;
             if (pre_ok) {
+                float* bias_s = reinterpret_cast<float*>(smem + NST * STAGE + wave * 2048);      // (RES: the wave's transpose area is free)
+                if (RES && lane < 16) *reinterpret_cast<float4*>(bias_s + 4 * lane) = bias_l;
                 // sums + bias: the same fp32 addition epilogue8 performs first (v += bias), in the accumulator layout -- epilogue8 is then handed a zero addend
 #pragma unroll
                 for (int a = 0; a < NA; ++a)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 bj = RES ? *reinterpret_cast<const float4*>(bias_s + a * 32 + 8 * j + 4 * hi) : bn[a][j];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            acc[a][b][4 * j] += bn[a][j].x; acc[a][b][4 * j + 1] += bn[a][j].y; acc[a][b][4 * j + 2] += bn[a][j].z; acc[a][b][4 * j + 3] += bn[a][j].w;
+                        for (int b = 0; b < 2; ++b) {
+                            acc[a][b][4 * j] += bj.x; acc[a][b][4 * j + 1] += bj.y; acc[a][b][4 * j + 2] += bj.z; acc[a][b][4 * j + 3] += bj.w;
                         }
-#pragma unroll
-                for (int a = 0; a < NA; ++a)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int n = ci.n0 + wn0 + a * 32 + 16 * t + 8 * hi, m = ci.m0 + wm0 + 32 + col;
-                        rq[a][t] = make_uint4(0, 0, 0, 0);
-                        if (RES && m < p.M && n + 8 <= p.N) rq[a][t] = *reinterpret_cast<const uint4*>(p.res + (size_t)m * p.res_ld + n);
                     }
             }
             // Row-major 16-bit outputs (GEGLU included) of a tile without a channel tail leave through a WAVE-PRIVATE 2 KB transpose in LDS: the
             // register layout gives a lane 8 channels of ONE row, so a direct store instruction touches 32 rows with 32 (GEGLU: 16) bytes each --
             // 16-byte fragments that the L2 takes at its request rate, not its byte rate (84 MB drained at 2.5 TB/s, a plain fill writes at 6.2:
             // profiles/r5d_write_bw_probe.jsonl).  Through the transpose 4 consecutive lanes store 64 contiguous bytes of a row.
-            const bool stage_ok = !RES && slab == nullptr && p.mode == OUT_ROWMAJOR && !p.out_f32 && ci.n0 + BN <= p.N;     // (with a residual: direct stores -- the outputs are
+            if constexpr (RES) {
+                // (round 6) residual tiles -- the launcher sends only row-major 16-bit outputs with whole 128-channel tiles here: the two 32-row halves
+                // of the wave tile are software-pipelined so that at most 16 residual registers are alive beside the accumulators: the results of rows
+                // b = 0 are finished into 16 packed registers (their accumulators and residual chunks die), THEN the residual of rows b = 1 is requested,
+                // then rows b = 0 are stored -- every load still precedes every store -- and rows b = 1 follow.  Holding both halves' residual across the
+                // whole epilogue (round 5) sat at the 168-register cap with 14 VGPRs in scratch.
+                uint4 pk0[NA][2];
+                auto finish = [&](int a, int b, int t, const uint4& rr) __attribute__((always_inline)) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[a][b][8 * t + e]), __float_as_uint(acc[a][b][8 * t + 4 + e]), false, false);
+                        v[e] = __uint_as_float(r[0]); v[4 + e] = __uint_as_float(r[1]);
+                    }
+                    uint4 pk = make_uint4(0, 0, 0, 0);
+                    epilogue8<F16>(p, v, ci.m0 + wm0 + b * 32 + col, ci.n0 + wn0 + a * 32 + 16 * t + 8 * hi, 8, HWo, true, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), true, rr, &pk);
+                    return pk;
+                };
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) pk0[a][t] = finish(a, 0, t, rp[a][t]);
+                const int m1 = ci.m0 + wm0 + 32 + col;
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        rq[a][t] = make_uint4(0, 0, 0, 0);
+                        if (m1 < p.M) rq[a][t] = *reinterpret_cast<const uint4*>(p.res + (size_t)m1 * p.res_ld + ci.n0 + wn0 + a * 32 + 16 * t + 8 * hi);
+                    }
+                if (m1 - 32 < p.M) {
+                    bf16_t* orow = reinterpret_cast<bf16_t*>(p.out) + (size_t)(m1 - 32) * p.out_ld + ci.n0 + wn0 + 8 * hi;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) *reinterpret_cast<uint4*>(orow + a * 32 + 16 * t) = pk0[a][t];
+                }
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) pk0[a][t] = finish(a, 1, t, rq[a][t]);
+                if (m1 < p.M) {
+                    bf16_t* orow = reinterpret_cast<bf16_t*>(p.out) + (size_t)m1 * p.out_ld + ci.n0 + wn0 + 8 * hi;
+#pragma unroll
+                    for (int a = 0; a < NA; ++a)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) *reinterpret_cast<uint4*>(orow + a * 32 + 16 * t) = pk0[a][t];
+                }
+            } else {
+            const bool stage_ok = slab == nullptr && p.mode == OUT_ROWMAJOR && !p.out_f32 && ci.n0 + BN <= p.N;     // (with a residual: direct stores -- the outputs are
                                                                                                                               // small there and the prefetched residual fills the registers)
             if (stage_ok) {
                 const bool geglu = p.act == ACT_GEGLU;
@@ -273,7 +336,7 @@ __global__ __launch_bounds__((BM / 32) * 64 + (BM / 64) * 64, 3) void gemm_dma25
                         const int n = ci.n0 + wn0 + a * 32 + 16 * t + 8 * hi;
                         uint4 pk = make_uint4(0, 0, 0, 0);
                         if (m < p.M) {
-                            if (pre_ok) epilogue8<F16>(p, v, m, n, 8, HWo, true, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), RES, b == 0 ? rp[a][t] : rq[a][t], &pk);
+                            if (pre_ok) epilogue8<F16>(p, v, m, n, 8, HWo, true, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), false, make_uint4(0, 0, 0, 0), &pk);
                             else epilogue8<F16>(p, v, m, n, 8, HWo, false, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), false, make_uint4(0, 0, 0, 0), &pk);
                         }
                         return pk;
@@ -329,13 +392,14 @@ __global__ __launch_bounds__((BM / 32) * 64 + (BM / 64) * 64, 3) void gemm_dma25
                         if (m < p.M && n < p.N) {
                             const int nv = (n + 8 <= p.N) ? 8 : 4;
                             if (slab) slab_store8(slab, (size_t)m * p.N + n, make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), nv == 8, false);
-                            else if (pre_ok) epilogue8<F16>(p, v, m, n, nv, HWo, true, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), RES && nv == 8, b == 0 ? rp[a][t] : rq[a][t]);
+                            else if (pre_ok) epilogue8<F16>(p, v, m, n, nv, HWo, true, make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0));
                             else epilogue8<F16>(p, v, m, n, nv, HWo);
                         }
                     }
                 }
             }
             }
+            }       // !RES
         }
         zero_acc();
     }
@@ -351,7 +415,7 @@ int launch_dma256_v(const ConvGemmParams& p, bool persistent, hipStream_t s, con
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return imd_set_error("%s: cannot identify the current device", what);
     constexpr int LDS = NST * (BM + BN) * G2_ROWB + (BM / 32) * 2048;      // ring + the consumer waves' 2 KB store-transpose areas
-    constexpr int WG_PER_CU = BM == 256 ? 1 : 2;
+    constexpr int WG_PER_CU = BM >= 192 ? 1 : 2;
     static_assert(LDS * WG_PER_CU <= 160 * 1024, "ring + transpose areas must fit the CU's LDS");
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
@@ -370,21 +434,23 @@ int launch_dma256_v(const ConvGemmParams& p, bool persistent, hipStream_t s, con
     const long items = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.split_k;
     const long slots = (long)n_cu * WG_PER_CU;
     const long grid = persistent ? (items < slots ? items : slots) : items;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((BM / 32) * 64 + (BM / 64) * 64), LDS, s, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((G2Waves<BM>::NCW + G2Waves<BM>::NPROD) * 64), LDS, s, p);
     return imd_check_launch(what);
 }
 
 template <int BM, int BN, int NST>
 int launch_dma256(const ConvGemmParams& p, bool persistent, hipStream_t s, const char* what) {
     const bool pre = p.rowvec == nullptr && p.split_k <= 1, res = p.res != nullptr;
-    if (!pre) return launch_dma256_v<BM, BN, NST, false, false>(p, persistent, s, what);      // (the generic epilogue8 path fetches what it needs itself)
+    // (the generic epilogue8 path fetches what it needs itself; the residual-prefetching form takes row-major 16-bit outputs with whole channel tiles only)
+    if (!pre || (res && (p.mode != OUT_ROWMAJOR || p.out_f32 || p.act == ACT_GEGLU || (p.N % BN) != 0 || (p.res_ld % 8) != 0 || (p.out_ld % 8) != 0)))
+        return launch_dma256_v<BM, BN, NST, false, false>(p, persistent, s, what);
     return res ? launch_dma256_v<BM, BN, NST, true, true>(p, persistent, s, what) : launch_dma256_v<BM, BN, NST, true, false>(p, persistent, s, what);
 }
 
 }  // namespace
 
-// tile configs 30 (256 x 128 x 64, three stages, persistent) and 31 (the same, one item per workgroup); K slices go to fp32 slabs and finish with the
-// tiled kernels' second launch.  (A 256 x 256 x 64 two-stage form behind the same template -- tile config 32 of the first draft -- was slower on every
+// tile configs 30 (256 x 128 x 64, three stages, persistent), 31 (the same, one item per workgroup) and 32 (192 x 128 x 64, persistent: round 6, for
+// tile counts that strand CUs at 256 rows); K slices go to fp32 slabs and finish with the tiled kernels' second launch.  (A 256 x 256 x 64 two-stage form behind the same template -- tile config 32 of the first draft -- was slower on every
 // feed-forward shape, 88-107 us against 55-97, profiles/r5b_gemm256_bench.jsonl: one stage of lead is not enough; it is not built.)
 int imd_launch_gemm_dma256(const ConvGemmParams& p_in, int form, hipStream_t s) {
     ConvGemmParams p = p_in;
@@ -397,6 +463,7 @@ int imd_launch_gemm_dma256(const ConvGemmParams& p_in, int form, hipStream_t s) 
     switch (form) {
         case 0: return launch_dma256<256, 128, 3>(p, true, s, "gemm_dma256 (256x128, persistent)");
         case 1: return launch_dma256<256, 128, 3>(p, false, s, "gemm_dma256 (256x128)");
+        case 2: return launch_dma256<192, 128, 3>(p, true, s, "gemm_dma256 (192x128, persistent)");
         default: return imd_set_error("gemm_dma256: unknown form %d", form);
     }
 }

@@ -230,7 +230,9 @@ class PipelineBase:
         # rows [0,B): prompt (+garment), rows [B,2B): negative prompt, no garment -> ehs rows shared per half
         ehs = torch.cat([prompt_embeds[:1], negative_prompt_embeds[:1]]).to(device=dev, dtype=dt).contiguous()
         mask_rows = torch.cat([torch.ones(B), torch.zeros(B)]).to(device=dev, dtype=torch.float32)
-        cak = {"sa_hidden_states": sa_hidden_states, "sa_batch_mask": mask_rows}
+        # sa_pair_layout: the mask above IS "garment on for rows [0, B), off for rows [B, 2B)" -- together with cfg_pair (identical latents in
+        # the two halves) it lets the engine run the first hybrid block's self-attention phase once per image (unet.call_pair_half)
+        cak = {"sa_hidden_states": sa_hidden_states, "sa_batch_mask": mask_rows, "sa_pair_layout": True}
         ctrl_img = ctrl_ehs = None
         if control is not None:
             img = control["image"]

@@ -146,6 +146,7 @@ FUSED_FF_MIN_ROWS = 24576  # below this the 128-row workgroups cannot fill the c
 import os as _os
 FUSED_GN_STATS = _os.environ.get("IMD_FUSED_GN_STATS", "1") != "0"   # 3x3 convs on the halo-patch kernel emit the GroupNorm statistics of their output from the epilogue (A/B switch)
 CFG_PAIR_DEDUP = _os.environ.get("IMD_CFG_PAIR_DEDUP", "1") != "0"   # sampling loop: conv_in + first resnet once for the two identical CFG halves (A/B switch)
+CFG_PAIR_ATTN = _os.environ.get("IMD_CFG_PAIR_ATTN", "1") != "0"     # ... and the first hybrid block up to its self-attention phase (unet.Transformer2D.call_pair_half; A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 GEMM_EVENT_HOOK = None     # tools/insitu_conv.py sets this to a dict: every conv_gemm launch is bracketed by HIP events, keyed by (shape key, cfg, split)
@@ -313,7 +314,7 @@ def conv_gemm(
                 cfg, split_k = -1, 0
             if cfg in (12, 13, 14, 15) and not lib.imd_row_linear_supported(C.byref(p)):
                 cfg, split_k = -1, 0
-            if cfg in (16, 17, 19, 25, 27, 30, 31) and not lib.imd_gemm_dma_supported(C.byref(p)):
+            if cfg in (16, 17, 19, 25, 27, 30, 31, 32) and not lib.imd_gemm_dma_supported(C.byref(p)):
                 cfg, split_k = -1, 0
             if (cfg in (18, 20) and (taps != 9 or Cin % 32 or stride not in (1, 2) or gn is not None)) or \
                     (cfg in (26, 28) and (taps != 9 or Cin % 64 or stride not in (1, 2) or gn is not None)):
@@ -501,9 +502,16 @@ def proj_counters(n: int, device) -> torch.Tensor:
     return t
 
 
+def attention_dup_supported(H: int, N: int, D: int) -> bool:
+    """Can imd_attention also store the first-phase result to ``out_dup`` (ABI v9)?  Head dim 40, N >= 512: the 64x64-level blocks."""
+    return bool(L.load().imd_attention_dup_supported(H, N, D))
+
+
 def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=None, scale2=None,
-              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False, k_pad_one=False, proj=None):
+              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False, k_pad_one=False, proj=None, out_dup=None):
     """``k_pad_one``: k1 (and k2) came from :func:`k_buffer`, i.e. their pad column D holds 1.0 (see the header).
+    ``out_dup`` [B, N, C]: also receives softmax(Q K1^T) V1 of every batch entry (the paired uncond rows of a CFG batch's first hybrid
+    block, :func:`attention_dup_supported`).
     ``proj`` = (w [C, C], bias [C] fp32 | None, residual [B, N, C] | None, proj_out [B, N, C]): the out-projection fused into the
     launch (:func:`attention_proj_supported`); returns proj_out then."""
     ensure_device(q.device)
@@ -521,6 +529,10 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
     p.causal = int(causal)
     p.k_pad_one = int(bool(k_pad_one))
     p.flags = _attn_call_flags()
+    if out_dup is not None:
+        if out_dup.numel() != out.numel():
+            raise L.ImdError("attention: out_dup must have the shape of out")
+        p.out_dup = _dev(out_dup, dt, "out_dup")
     ret = out
     if proj is not None:
         pw, pb, pres, pout = proj

@@ -290,6 +290,9 @@ class TransformerBlock:
 
     def __call__(self, h, ehs, cak):
         h = self.attn1(h, encoder_hidden_states=None, residual=h, layernorm=(self.norm1, 1e-5), **cak)
+        return self.after_attn1(h, ehs, cak)
+
+    def after_attn1(self, h, ehs, cak):
         h = self.attn2(h, encoder_hidden_states=ehs, residual=h, layernorm=(self.norm2, 1e-5), **cak)
         B, L, Cc = h.shape
         if self.ff_fused is not None and ops.FUSED_FF and B * L >= ops.FUSED_FF_MIN_ROWS:
@@ -314,6 +317,36 @@ class Transformer2D:
         for blk in self.transformer_blocks:
             h = blk(h, ehs, cak)
         return self.proj_out(h.view(B, H, W, Cc), res=x)
+
+    # ---- first hybrid block of a CFG batch (round 6) ----
+    def pair_half_ok(self, x_half, cak) -> bool:
+        """Can this transformer run norm -> proj_in -> norm1 -> q / k / v -> the self-attention phase ONCE for the two identical halves of
+        a CFG batch?  Needs the caller's word that the garment branch is on for the first half only (``sa_pair_layout``, set where the
+        pipeline builds ``sa_batch_mask``), a hybrid processor that opted in (``fused_pair_half``) with its garment tokens present, and
+        the attention kernel's duplicated first-phase store for this shape."""
+        blk = self.transformer_blocks[0]
+        proc = blk.attn1.processor
+        sa = cak.get("sa_hidden_states")
+        Bh, H, W, Cc = x_half.shape
+        return bool(cak.get("sa_pair_layout") and cak.get("sa_batch_mask") is not None and sa is not None
+                    and getattr(proc, "fused_pair_half", False) and getattr(proc, "fused_residual", False)
+                    and getattr(proc, "name", None) in sa and not ops.ATTN_FP8 and not ops.FUSED_OUT_PROJ
+                    and ops.attention_dup_supported(blk.attn1.heads, H * W, Cc // blk.attn1.heads))
+
+    def call_pair_half(self, x_half, ehs, cak):
+        """``x_half`` [B/2, H, W, C]: the block input of the cond rows == that of the uncond rows.  -> the block output for all B rows.
+        Everything up to and including the self-attention phase of attn1 runs on B/2 rows; the attention launch writes the hybrid result
+        of the cond rows and their first phase as the uncond rows' result (bit-identical to the B-row form: same kernels on the same
+        values); from the out-projection on the two halves differ and the block continues on B rows."""
+        Bh, H, W, Cc = x_half.shape
+        blk = self.transformer_blocks[0]
+        x_full = ops.repeat_batch(x_half)                                  # the transformer's own residual (and the caller's skip tensor)
+        h = ops.group_norm(x_half, self.norm.weight, self.norm.bias, groups=self.groups, eps=1e-6, silu=False)
+        h = self.proj_in(h).view(Bh, H * W, Cc)
+        h_full = ops.repeat_batch(h)                                       # attn1's block residual, one copy per half
+        h = blk.attn1(h, encoder_hidden_states=None, residual=h_full, layernorm=(blk.norm1, 1e-5), imd_pair_half=True, **cak)
+        h = blk.after_attn1(h, ehs, cak)
+        return self.proj_out(h.view(2 * Bh, H, W, Cc), res=x_full)
 
 
 class ResnetBlock:
@@ -414,19 +447,22 @@ class _Encoder(PretrainedMixin):
         e = ops.linear(e, self.time_lin2.weight, self.time_lin2.bias, act=ops.ACT_SILU)
         return ops.linear(e, self.temb_proj.weight, self.temb_proj.bias, out_f32=True)     # [B, sum(Cout)] fp32
 
-    def _run_down(self, x, temb_all, ehs, cak, pair_skip=None):
+    def _run_down(self, x, temb_all, ehs, cak, pair_skip=None, pair_attn_done=False):
         """``pair_skip``: the caller has already run conv_in and the first resnet on ONE half of a CFG batch whose halves are identical
-        up to there (``x`` = that resnet's output repeated for both halves, ``pair_skip`` = the half-batch conv_in output)."""
+        up to there (``x`` = that resnet's output repeated for both halves, ``pair_skip`` = the half-batch conv_in output);
+        ``pair_attn_done``: ... and the first transformer as well (``Transformer2D.call_pair_half``; ``x`` = its output)."""
         skips = [x if pair_skip is None else pair_skip]
         first = pair_skip is not None
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
                 if first:
                     first = False                       # (already applied by the caller)
+                    if blk.attentions and not pair_attn_done:
+                        x = blk.attentions[j](x, ehs, cak)
                 else:
                     x = r(x, temb_all)
-                if blk.attentions:
-                    x = blk.attentions[j](x, ehs, cak)
+                    if blk.attentions:
+                        x = blk.attentions[j](x, ehs, cak)
                 skips.append(x)
             if blk.downsampler is not None:
                 x = blk.downsampler(x, stride=2, gn_stats_groups=self.cfg["norm_num_groups"])   # feeds the next level's norm1 (K-sliced: statistics from the finish launch)
@@ -521,8 +557,15 @@ class UNet2DConditionModel(_Encoder):
         temb_all = self._time_embed(timestep, B, x.device)
         if cfg_pair and B % 2 == 0 and ops.CFG_PAIR_DEDUP:
             h0 = self.conv_in(x[:B // 2])
-            h = ops.repeat_batch(self.down_blocks[0].resnets[0](h0, temb_all))
-            h, skips = self._run_down(h, temb_all, ehs, cak, pair_skip=h0)
+            blk0 = self.down_blocks[0]
+            r0 = blk0.resnets[0](h0, temb_all)
+            # the first transformer's input is still identical for the two halves: norm / proj_in / norm1 / q-k-v / the self-attention
+            # phase run once per image (Transformer2D.call_pair_half); the halves part ways at attn1's out-projection
+            if ops.CFG_PAIR_ATTN and blk0.attentions and blk0.attentions[0].pair_half_ok(r0, cak):
+                h = blk0.attentions[0].call_pair_half(r0, ehs, cak)
+                h, skips = self._run_down(h, temb_all, ehs, cak, pair_skip=h0, pair_attn_done=True)
+            else:
+                h, skips = self._run_down(ops.repeat_batch(r0), temb_all, ehs, cak, pair_skip=h0)
         else:
             h = self.conv_in(x)
             h, skips = self._run_down(h, temb_all, ehs, cak)

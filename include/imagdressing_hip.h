@@ -136,6 +136,13 @@ typedef struct imd_attn_params {
     uint16_t* proj_out;       /* [B, N, proj_out_ld] */
     int proj_res_ld, proj_out_ld;
     int* proj_counters;       /* >= B * ceil(N / 256) ints, ZERO on entry, left zero (one per batch entry and 256-row block) */
+    /* Duplicated first-phase output (ABI v9; imd_attention_dup_supported(): head dim 40, N >= 512, k_pad_one, no causal mask, no fused
+     * out-projection): when out_dup is given, softmax(Q K1^T) V1 of batch entry b -- rounded to the element type exactly as a row
+     * WITHOUT a second key set stores it -- is also written to out_dup[b, :, :] (same out_ld).  For the first hybrid block of a CFG
+     * batch, where the cond and uncond rows of an image still have identical Q / K / V: one launch over the B cond rows produces the
+     * cond rows (`out`) and the uncond rows (`out_dup`), bit-identical to a 2B-row launch (RefSAttnProcessor2_0 with and without
+     * sa_hidden_states on the same hidden states, attention_processor.py:589-612). */
+    uint16_t* out_dup;
 } imd_attn_params;
 
 /* Fused feed-forward of a transformer block on the 64x64 level (ff_fused.hip), C = 320, inner = 1280:
@@ -254,6 +261,8 @@ int imd_attention_fp8(const imd_attn_params* p, int eq, int ek, int ev, void* st
  *         at position 32 ((k >> 3) & 1) + 8 ((k >> 4) & 3) + (k & 7) (the order the kernel's packed P comes out in). */
 int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long count, int LP, int exp2_scale, float pad_val, int dtype,
                           void* stream);
+/* 1 iff imd_attention accepts imd_attn_params.out_dup for this head count / query count / head dim (with k_pad_one = 1) */
+int imd_attention_dup_supported(int H, int N, int D);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
 /* performance knobs (results are identical for every accepted setting up to fp32 summation order).  knob 0: head-dim-40 attention

@@ -311,6 +311,40 @@ def test_full_pipeline_deterministic(full_pipe):
 
 
 @torch.no_grad()
+def test_full_pipeline_first_hybrid_block_once_per_image_is_bit_identical(full_pipe):
+    """Round 6: in ``down_blocks.0.attentions.0`` the cond and uncond rows of an image still carry identical hidden states, so norm ->
+    proj_in -> norm1 -> q / k / v -> the self-attention phase run once per image and the attention launch stores that phase twice
+    (``Transformer2D.call_pair_half``, ``imd_attn_params.out_dup``: bit-identical at the kernel level,
+    ``test_full_attention_duplicated_first_phase_is_bit_identical``).  At the pipeline level the two forms run the SAME arithmetic through
+    different launch geometries (half-batch GroupNorm statistics come from the producing convolution's epilogue instead of a statistics
+    pass, the half-batch projections pick other tile configurations): they differ in fp32 summation order only, i.e. like two
+    realisations of the 16-bit rounding noise -- the bars of ``test_full_pipeline_batched_equals_sharded``.  The path is really taken
+    (the first level-0 attention launch runs B instead of 2B rows: seen through the hook)."""
+    from imagdressing_amd import ops
+    pipe, inp, _ = full_pipe
+    assert ops.CFG_PAIR_ATTN
+    seen = []
+    ops.ATTN_EVENT_HOOK = {"match": lambda **kw: (seen.append((kw["B"], kw["N"], kw["L2"])) or False), "events": []}
+    try:
+        a = run_pipe(pipe, inp, slice(0, 4), steps=5)
+    finally:
+        ops.ATTN_EVENT_HOOK = None
+    assert (4, 4096, 4096) in seen and (8, 4096, 4096) in seen            # the de-duplicated first block and the ordinary ones
+    ops.CFG_PAIR_ATTN = False
+    seen.clear()
+    ops.ATTN_EVENT_HOOK = {"match": lambda **kw: (seen.append((kw["B"], kw["N"], kw["L2"])) or False), "events": []}
+    try:
+        b = run_pipe(pipe, inp, slice(0, 4), steps=5)
+    finally:
+        ops.ATTN_EVENT_HOOK = None
+    assert (4, 4096, 4096) not in seen
+    assert torch.isfinite(a).all()
+    bar = 4e-2 if full_pipe[2] == torch.bfloat16 else 6e-3
+    scale = b.pow(2).mean().sqrt()
+    assert (a - b).pow(2).mean().sqrt() < bar * scale, ((a - b).pow(2).mean().sqrt() / scale).item()
+
+
+@torch.no_grad()
 def test_full_pipeline_batched_equals_sharded(full_pipe):
     """Batched generation is DEFINED as independent runs: the 4-image batch, two 2-image shards
     (what 2 ranks compute, imagdressing_amd/dist.py::shard_bounds) and a single-image run agree.  They differ only in
@@ -414,6 +448,32 @@ def test_full_attention_benchmarked_instantiation_vs_oracle(ops, dt, N, M, spike
         bad = err > atol + rtol * ref.abs()
         assert torch.isfinite(out).all()
         assert not bad.any(), f"k_pad_one={pad_one}: {int(bad.sum())} of {bad.numel()} off; max err {err.max().item():.4g}; ref max {ref.abs().max().item():.3g}"
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("N,M", [(4096, 4096), (1000, 700), (640, 5120)])
+def test_full_attention_duplicated_first_phase_is_bit_identical(ops, dt, N, M):
+    """imd_attn_params.out_dup (ABI v9): a launch over the B cond rows of a CFG batch's first hybrid block that also stores each row's
+    first-phase result == the 2B-row launch in which rows [B, 2B) repeat the same Q / K / V without the garment branch
+    (RefSAttnProcessor2_0 with / without sa_hidden_states on identical hidden states, attention_processor.py:589-612).  Bit for bit,
+    both element types, ragged N, a row whose garment weight is 0 (single-phase row: both outputs equal), both default variants."""
+    B, H, D = 4, 8, 40
+    q, k, vt, kr, vr, _ = attn_operands(ops, dt, B=B, N=N, M=M, seed=5)
+    s2h = torch.tensor([1.0, 0.5, 0.0, 2.0], device="cuda")                  # (row 2: garment branch off -> one phase)
+    s2 = torch.cat([s2h, torch.zeros(B, device="cuda")])
+    ref = run_attn(ops, torch.cat([q, q]), torch.cat([k, k]), torch.cat([vt, vt]), kr, vr, s2)
+    for variant in (13, 12):
+        with ops.tuning_scope(attn_variant=variant):
+            out = torch.empty(2 * B, N, H * D, dtype=dt, device="cuda")
+            ops.attention(q, k, vt, out[:B], B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M, L2P=ops.pad64(M),
+                          kv2_bdiv=B, k_pad_one=True, out_dup=out[B:])
+            ref_v = run_attn(ops, torch.cat([q, q]), torch.cat([k, k]), torch.cat([vt, vt]), kr, vr, s2)
+        assert torch.equal(out, ref_v), f"variant {variant}"
+        assert torch.equal(ref_v, ref) or variant == 12                          # (12 / 13 differ only under overflow: not here)
+    assert torch.equal(out[2], out[B + 2]) and not torch.equal(out[0], out[B])
+    assert ops.attention_dup_supported(H, N, D) and not ops.attention_dup_supported(H, 256, D) and not ops.attention_dup_supported(H, N, 80)
+    with pytest.raises(ops.L.ImdError):                                          # register staging (no k_pad_one) has no duplicated store
+        ops.attention(q, k, vt, out[:B], B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k_pad_one=False, out_dup=out[B:])
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])

@@ -85,7 +85,7 @@ def test_linear_epilogues(ops, dt):
 @DTS
 @pytest.mark.parametrize("M,N,K,split,cfg", [(512, 1280, 11520, 6, 0), (200, 320, 2304, 3, 2), (2048, 132, 4096, 4, 1), (64, 64, 8192, 8, -1), (300, 640, 2560, 5, 6), (130, 64, 4096, 7, 7), (600, 384, 2048, 3, 9), (520, 520, 1024, 2, 10),
                                                   (512, 1280, 5120, 3, 17), (300, 132, 2048, 4, 17), (512, 1280, 5120, 3, 25), (300, 132, 2048, 4, 27),
-                                                  (512, 1280, 5120, 3, 30), (300, 132, 2048, 4, 31), (1000, 640, 2560, 2, 31), (4096, 640, 2560, 5, 30)])
+                                                  (512, 1280, 5120, 3, 30), (300, 132, 2048, 4, 31), (1000, 640, 2560, 2, 31), (4096, 640, 2560, 5, 30), (1000, 640, 2560, 2, 32), (700, 132, 2048, 4, 32)])
 def test_linear_split_k(ops, M, N, K, split, cfg, dt):
     """K slices into fp32 slabs + fixed-order finish kernel == unsplit result (bias + residual + SiLU epilogue)."""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
@@ -287,12 +287,12 @@ def test_row_qkv(ops, ln, dt):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 320, 320), (1000, 2560, 640), (77, 64, 768), (520, 1284, 1280), (2048 + 19, 520, 128)])
-@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27, 30, 31])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27, 30, 31, 32])
 @DTS
 def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
     """tile configs 16 (256 x 256 x 64, two stages), 17 and 19 (128 x 128 x 32, three- / four-stage ring, round 3), 25 and 27 (128 x 128 x 64:
     128-byte rows, two / three stages, round 4), 30 / 31 (gemm_dma256.hip, round 5: 256 x 128 tiles, producer / consumer waves, persistent item loop,
-    epilogue from registers): both operands by LDS-DMA == x W^T + b, with the shared epilogues"""
+    epilogue from registers), 32 (round 6: the same kernel with 192-row tiles, six consumer + four producer waves): both operands by LDS-DMA == x W^T + b, with the shared epilogues"""
     x = rnd(1, M, K).to(dt); w = rnd(2, N, K, scale=K ** -0.5).to(dt); b = rnd(3, N); res = rnd(4, M, N).to(dt)
     base = x.float() @ w.float().t() + b
     assert_close(ops.linear(dev(x), dev(w), dev(b), cfg=cfg), base, what="gemm_dma")
@@ -307,7 +307,7 @@ def test_linear_gemm_dma(ops, M, N, K, dt, cfg):
         ops.linear(dev(rnd(1, 64, 72).to(dt)), dev(rnd(2, 64, 72).to(dt)), cfg=cfg)           # K % 64 != 0: refused
 
 
-@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27, 30, 31])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 25, 27, 30, 31, 32])
 @DTS
 def test_gemm_dma_head_split(ops, dt, cfg):
     """head-split q / k / v epilogue through tile config 16 (the 32x32-level projection: 8 heads x 80)"""
@@ -325,7 +325,7 @@ def test_gemm_dma_head_split(ops, dt, cfg):
 
 @pytest.mark.parametrize("M,N,K,act,split", [(8192, 5120, 640, "geglu", 1), (2048, 10240, 1280, "geglu", 1), (8192, 640, 2560, "res", 1),
                                              (8192, 640, 2560, "res", 2), (8192 + 70, 1920, 640, "heads", 1)])
-@pytest.mark.parametrize("cfg", [30, 31])
+@pytest.mark.parametrize("cfg", [30, 31, 32])
 @DTS
 def test_gemm_dma256_persistent_item_loop(ops, M, N, K, act, split, cfg, dt):
     """gemm_dma256.hip at the feed-forward shapes it was written for (BASELINE configs[1], batch 4: GEGLU 8192 x 5120 x 640 and

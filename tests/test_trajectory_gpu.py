@@ -5,9 +5,11 @@ that what only compounds over a run is pinned too: the fp32 latent state through
 reused across all steps, the ``cfg_pair`` de-duplication, HIP-graph replay at full width, the batch-4 call of the bench workload.
 
 Bars (final latent and every kept intermediate latent; rel-rms = rms error / rms of the oracle latent, worst element in units of the
-oracle latent's sigma): fp16 0.5 % / 0.03 sigma; bf16 (8 mantissa bits) 3 % / 0.2 sigma.  Measured (profiles/r5a_trajectory_parity.jsonl):
-fp16 0.16-0.22 % / 0.007-0.013 sigma, bf16 1.2-1.8 % / 0.05-0.10 sigma -- the per-forward error (fp16 0.1 %, bf16 1.2 % rms) does NOT grow along the
-20 / 50 steps; HIP-graph replay of the batch-4 call is bit-identical to the eager run."""
+oracle latent's sigma), round 6: at most 1.5x the worst figure MEASURED for the case (profiles/r5a_trajectory_parity.jsonl), so that a 2x
+regression fails -- configs[0] / configs[1]: fp16 0.3 % / 0.015 sigma (measured 0.16-0.19 % / 0.008), bf16 (8 mantissa bits)
+2 % / 0.1 sigma (1.2-1.5 % / 0.05-0.06); configs[2] / configs[4] (10 steps, ControlNet residuals / 96x72 inpainting): fp16 0.33 % / 0.02 sigma
+(0.21-0.22 % / 0.010-0.013), bf16 2.7 % / 0.155 sigma (1.7-1.8 % / 0.08-0.10).  The per-forward error (fp16 0.1 %, bf16 1.2 % rms) does NOT grow
+along the 20 / 50 steps; HIP-graph replay of the batch-4 call is bit-identical to the eager run."""
 import os
 
 import pytest
@@ -17,7 +19,8 @@ pytestmark = pytest.mark.gpu
 
 from tests.trajectory_fixture import CASES, FILE  # noqa: E402
 
-BARS = {torch.float16: dict(rel_rms=5e-3, max_sigma=0.03), torch.bfloat16: dict(rel_rms=3e-2, max_sigma=0.2)}
+BARS = {torch.float16: dict(rel_rms=3e-3, max_sigma=0.015), torch.bfloat16: dict(rel_rms=2e-2, max_sigma=0.1)}              # configs[0] / configs[1]
+BARS_OTHER = {torch.float16: dict(rel_rms=3.3e-3, max_sigma=0.02), torch.bfloat16: dict(rel_rms=2.7e-2, max_sigma=0.155)}     # configs[2] / configs[4]
 
 
 def _record(dtype, res):
@@ -79,7 +82,7 @@ def test_full_width_trajectory_other_configs_vs_committed_oracle(gold, name, dty
         pytest.fail(f"{name} missing from trajectory.pt")
     res = measure_trajectory_parity(torch.device("cuda"), dtype, cases=(name,), batch4=False, graph=False)
     _record(dtype, res)
-    bar = BARS[dtype]
+    bar = BARS_OTHER[dtype]
     spec = CASES[name]
     for seed in spec["seeds"]:
         ent = res[name][f"seed{seed}"]
