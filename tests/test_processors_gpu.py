@@ -1,6 +1,9 @@
 """The HIP processors / resamplers (through the plugin surface and the C ABI) against the committed golden
 vectors that the REFERENCE's own source produced (tests/golden/*.pt, oracle/make_golden.py).
-fp16 is held to the north-star atol 1e-2; bf16 to 4e-2 (8 mantissa bits; see DESIGN.md 'Numerics')."""
+Bars (round 6) sit at <= 2x the worst MEASURED error of their family (profiles/r6c_processor_parity.jsonl), so that a 2x regression fails:
+attention processors fp16 2e-3 + 0.05 % of |ref| (measured <= 2.0e-3 at |ref| 4.6 with the fused residual, <= 1.1e-3 otherwise; the
+north-star tolerance is atol 1e-2), bf16 1.5e-2 + 0.5 % (measured <= 1.5e-2 at |ref| 4.8, <= 8.5e-3 otherwise); the Perceiver resamplers
+(four layers deep, fp32 softmax, |out| up to 4.4) fp16 1e-2 (measured 5.1e-3), bf16 4e-2 + 1 % (measured 4.1e-2 at |ref| 4.4)."""
 import pytest
 import torch
 
@@ -9,8 +12,10 @@ pytestmark = pytest.mark.gpu
 from tests.cases import cache_inputs, cross_inputs, hybrid_inputs, legacy_inputs, proj_plus_inputs, resampler_inputs  # noqa: E402
 
 DT = pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
-ATOL = {torch.float16: 1e-2, torch.bfloat16: 4e-2}
-RTOL = {torch.float16: 0.0, torch.bfloat16: 1e-2}     # bf16: + 1 % of |ref| (outputs reach |4.4|; one bf16 ulp there is 3.1e-2)
+ATOL = {torch.float16: 2e-3, torch.bfloat16: 1.5e-2}      # attention processors
+RTOL = {torch.float16: 5e-4, torch.bfloat16: 5e-3}
+ATOL_RS = {torch.float16: 1e-2, torch.bfloat16: 4e-2}     # resamplers
+RTOL_RS = {torch.float16: 0.0, torch.bfloat16: 1e-2}      # bf16: + 1 % of |ref| (outputs reach |4.4|; one bf16 ulp there is 3.1e-2)
 
 
 def make_attn(i, heads, dt):
@@ -27,18 +32,25 @@ def set_lora(proc, lw):
             layer.down.weight.copy_(lw[nm][0]); layer.up.weight.copy_(lw[nm][1])
 
 
-def check(got, ref, dt, what):
-    e = (got.float().cpu() - ref).abs()
-    try:        # measured figures -> gpurun_out/processor_parity.jsonl (written BEFORE the bar is applied; what the bars are set from)
+def _record(what, dt, e, bar, ref, **extra):
+    """measured figures -> gpurun_out/processor_parity.jsonl (written BEFORE the bar is applied; what the bars are set from)"""
+    try:
         import json, os
         os.makedirs("gpurun_out", exist_ok=True)
         with open("gpurun_out/processor_parity.jsonl", "a") as f:
-            f.write(json.dumps({"what": str(what), "dtype": str(dt), "max_abs_err": e.max().item(), "ref_max": ref.abs().max().item(),
-                                "worst_over_bar": (e / (ATOL[dt] + RTOL[dt] * ref.abs())).max().item()}) + "\n")
+            f.write(json.dumps(dict(what=str(what), dtype=str(dt), max_abs_err=e.max().item(), ref_max=ref.abs().max().item(),
+                                    worst_over_bar=(e / bar).max().item(), **extra)) + "\n")
     except OSError:
         pass
-    bad = e > ATOL[dt] + RTOL[dt] * ref.abs()
-    assert not bad.any(), f"{what}: {int(bad.sum())} elements off, max abs err {e.max().item():.4g} (atol {ATOL[dt]}, rtol {RTOL[dt]}, ref max {ref.abs().max().item():.3g})"
+
+
+def check(got, ref, dt, what, resampler=False):
+    atol, rtol = (ATOL_RS[dt], RTOL_RS[dt]) if resampler else (ATOL[dt], RTOL[dt])
+    e = (got.float().cpu() - ref).abs()
+    bar = atol + rtol * ref.abs()
+    _record(what, dt, e, bar, ref)
+    bad = e > bar
+    assert not bad.any(), f"{what}: {int(bad.sum())} elements off, max abs err {e.max().item():.4g} (atol {atol}, rtol {rtol}, ref max {ref.abs().max().item():.3g})"
 
 
 @DT
@@ -106,7 +118,7 @@ def test_cross_processor_vs_reference_golden(golden_processors, name, dt):
 
 
 # ---- the reference source at the BENCHMARKED kernel shape, a spiked ragged case, CacheAttn at real head dims ----------
-FULL_ATOL = {torch.float16: 1e-2, torch.bfloat16: 4e-2}
+FULL_ATOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}      # (round 6: <= 2x the measured 9e-4 / 7e-3; the spiked case has its own bars below)
 # + rtol |ref|: a logit of magnitude s is carried by 16-bit Q / K only to about s * 2^-11 (fp16) / s * 2^-8 (bf16); the spiked
 # key has logits up to ~15, i.e. its softmax weight -- and the output rows it dominates, |out| up to ~4 -- to 1 % / 8 %
 FULL_RTOL = {torch.float16: 1e-2, torch.bfloat16: 8e-2}
@@ -115,16 +127,11 @@ FULL_RTOL = {torch.float16: 1e-2, torch.bfloat16: 8e-2}
 def check_rows(got, ref, dt, what, spiked=False):
     e = (got.float().cpu() - ref).abs()
     # spiked bf16: the x4 tokens also scale V (|v| ~ 4): an 8 % weight error on a dominant key moves small output elements by ~0.1
-    atol = 1e-1 if (spiked and dt == torch.bfloat16) else FULL_ATOL[dt]
-    try:
-        import json, os
-        os.makedirs("gpurun_out", exist_ok=True)
-        with open("gpurun_out/processor_parity.jsonl", "a") as f:
-            f.write(json.dumps({"what": str(what), "dtype": str(dt), "spiked": bool(spiked), "max_abs_err": e.max().item(), "ref_max": ref.abs().max().item(),
-                                "worst_over_bar": (e / (atol + FULL_RTOL[dt] * ref.abs())).max().item()}) + "\n")
-    except OSError:
-        pass
-    bad = e > atol + FULL_RTOL[dt] * ref.abs()
+    atol = (1e-1 if dt == torch.bfloat16 else 1e-2) if spiked else FULL_ATOL[dt]
+    rtol = FULL_RTOL[dt] if spiked else {torch.float16: 1e-3, torch.bfloat16: 1e-2}[dt]
+    bar = atol + rtol * ref.abs()
+    _record(what, dt, e, bar, ref, spiked=bool(spiked))
+    bad = e > bar
     assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.numel()} elements off, max abs err {e.max().item():.4g}, ref max {ref.abs().max().item():.3g}"
 
 
@@ -307,7 +314,7 @@ def test_resampler_vs_reference_golden(golden_resampler, name, dt):
     m.load_state_dict(sd, strict=True)
     out = m(x.cuda().to(dt))
     assert out.dtype == dt and tuple(out.shape) == tuple(c["out"].shape)
-    check(out, c["out"], dt, name)
+    check(out, c["out"], dt, name, resampler=True)
 
 
 @DT
@@ -320,8 +327,8 @@ def test_proj_plus_vs_reference_golden(golden_resampler, dt):
     sd, idv, clip = proj_plus_inputs(c)
     m = ProjPlusModel()
     m.load_state_dict(sd, strict=True)
-    check(m(idv.cuda().to(dt), clip.cuda().to(dt)), c["out"], dt, "proj_plus")
-    check(m(idv.cuda().to(dt), clip.cuda().to(dt), shortcut=True, scale=0.7), c["out_shortcut"], dt, "proj_plus shortcut")
+    check(m(idv.cuda().to(dt), clip.cuda().to(dt)), c["out"], dt, "proj_plus", resampler=True)
+    check(m(idv.cuda().to(dt), clip.cuda().to(dt), shortcut=True, scale=0.7), c["out_shortcut"], dt, "proj_plus shortcut", resampler=True)
 
 
 @DT

@@ -9,6 +9,11 @@
 #   trace  TAG [bench args]        rocprofv3 --kernel-trace --stats of the quick bench -> gpurun_out/TAG_kernel_trace_summary.md
 #   ab-env TAG VAR V1 V2 [args]    same-box A/B of one environment variable, interleaved twice (quick bench)
 #   ab-lib TAG L1 L2 ...           same-box A/B of library builds imagdressing_amd/libimagdressing_hip_<L>.so ("cur" = shipped)
+#   ab-flags TAG V1 V2 [args]      same-box A/B of two values of tuning knob 2 (bench.py --gemm-flags), interleaved twice
+#   ab-table TAG T1 T2             same-box A/B of two tuning tables over the tuned workloads (512x512, 512x640, configs[2], configs[4]), interleaved twice
+#   retune TAG gemm_tune-args...   re-time one class of layers of the five tuned workloads (tools/gemm_tune.py ARGS: e.g. --only-linear --cands 30,32
+#                                  --min-k 64, or --only-conv3x3) and merge the winners (3 % hysteresis) into imagdressing_amd/gemm_tuning.json;
+#                                  the table before / after and the log -> gpurun_out/TAG_*
 #   pmc    OUT PATTERN cmd...      PMC counters of the kernels matching PATTERN in cmd (separate passes, --kernel-trace only)
 #   prof   TAG cmd...              rocprofv3 --kernel-trace --stats of any command -> gpurun_out/TAG_kernel_trace_summary.md (HEAD lines printed, default 30)
 #   run    TAG cmd...              any command, stdout+stderr -> gpurun_out/TAG.txt (tail printed)
@@ -48,6 +53,41 @@ case "$task" in
       if [ $lib = cur ]; then unset IMD_LIB_PATH; else export IMD_LIB_PATH=$R/imagdressing_amd/libimagdressing_hip_$lib.so; fi
       timeout 400 python bench.py --steps 3 --warmup 1 $QUICK 2>/dev/null | line "lib=$lib"
     done; done | tee gpurun_out/${tag}_ab.txt ;;
+  ab-flags)
+    tag="$1"; v1="$2"; v2="$3"; shift 3
+    for rep in 1 2; do for v in $v1 $v2; do
+      timeout 400 python bench.py --steps 3 --warmup 1 $QUICK --gemm-flags $v "$@" 2>/dev/null | line "gemm_flags=$v"
+    done; done | tee gpurun_out/${tag}_flags_ab.txt ;;
+  ab-table)
+    tag="$1"; A="$2"; B="$3"
+    ms() { python -c "import sys,json; print(json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])['ms_per_step'])"; }
+    for rep in 1 2; do for T in $A $B; do
+      export IMD_GEMM_TUNING=$T
+      a=$(timeout 300 python bench.py --steps 3 --warmup 1 $QUICK 2>/dev/null | ms)
+      b=$(timeout 300 python bench.py --steps 3 --warmup 1 $QUICK --width 512 --height 640 2>/dev/null | ms)
+      c=$(timeout 300 python tools/configs.py --config 3 --steps 10 2>/dev/null | ms)
+      d=$(timeout 300 python tools/configs.py --config 5 --steps 10 2>/dev/null | ms)
+      echo "table=$T  512x512_ms_per_bench_step=$a  512x640=$b  configs2_ms_per_ddim_step=$c  configs4_ms_per_ddim_step=$d"
+    done; done | tee gpurun_out/${tag}_table_ab.txt ;;
+  retune)
+    tag="$1"; shift
+    T=imagdressing_amd/gemm_tuning.json
+    cp $T gpurun_out/${tag}_table_before.json
+    i=0
+    for wl in "--config 1" "--config 1 --width 512 --height 640" "--config 1 --batch 1" "--config 3" "--config 5"; do
+      i=$((i+1))
+      timeout 600 python tools/gemm_tune.py "$@" $wl --out gpurun_out/gemm_tuning.json > gpurun_out/${tag}_retune_$i.log 2>&1 && cp gpurun_out/gemm_tuning.json $T
+      echo "workload $i ($wl): $(grep -c changed gpurun_out/${tag}_retune_$i.log) changed"
+    done
+    python - "$tag" <<'PY'
+import json, sys
+a = json.load(open(f"gpurun_out/{sys.argv[1]}_table_before.json"))["shapes"]; b = json.load(open("imagdressing_amd/gemm_tuning.json"))["shapes"]
+ch = {k: (a.get(k), b[k]) for k in b if a.get(k) != b[k]}
+print(len(ch), "entries changed")
+for k, (x, y) in sorted(ch.items()): print(k, x, "->", y)
+PY
+    cp $T gpurun_out/${tag}_table_after.json
+    cat gpurun_out/${tag}_retune_*.log | grep '^{' > gpurun_out/${tag}_retune_log.jsonl ;;
   prof)
     tag="$1"; shift
     mkdir -p gpurun_out/$tag
