@@ -405,8 +405,8 @@ def test_tuning_table_only_names_known_tile_configs():
             Ho, Wo = map(int, geom.split("x"))
             assert taps == 9 and M % (Ho * Wo) == 0, key
         for c in (ent["cfg"], ent["cfg_nosplit"]):
-            assert c in range(0, 32), (key, ent)
-            if c in (17, 19, 25, 27, 30, 31): assert K % 64 == 0 and taps == 1, key
+            assert c in range(0, 33), (key, ent)
+            if c in (17, 19, 25, 27, 30, 31, 32): assert K % 64 == 0 and taps == 1, key
             if c in (18, 20): assert taps == 9 and (K // 9) % 32 == 0, key
             if c in (26, 28): assert taps == 9 and (K // 9) % 64 == 0, key
             if c == 12: assert K == 320 and N <= 320 and N % 64 == 0 and taps == 1, key
