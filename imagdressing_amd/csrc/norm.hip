@@ -199,7 +199,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_coeffs_kernel(const GroupNormPa
     __shared__ float red_s[GN_THREADS], red_q[GN_THREADS];
     const int tid = threadIdx.x, b = blockIdx.x;
     const int cpg = p.C / p.G;
-    const int nchunks = gn_chunks(p.B, p.HW, p.C);
+    const int nchunks = p.nparts > 0 ? p.nparts : gn_chunks(p.B, p.HW, p.C);       // (nparts: partials written by the producer of x, as in gn_apply_kernel)
     const int parts = GN_THREADS / p.G;
     const int g = tid % p.G, part = tid / p.G;
     float S = 0.f, Q = 0.f;
@@ -406,6 +406,11 @@ static int gn_validate(const GroupNormParams& p) {
 int imd_launch_groupnorm_coeffs(const GroupNormParams& p, float* ca, float* cb, hipStream_t s) {
     int rc = gn_validate(p);
     if (rc) return rc;
+    if (p.nparts > 0) {              // statistics came with the tensor (convolution epilogue / finish launch): fold them, same order as gn_apply_kernel
+        if (p.nparts > 4096) return imd_set_error("groupnorm coeffs: nparts %d is implausible", p.nparts);
+        hipLaunchKernelGGL(gn_coeffs_kernel, dim3(p.B), dim3(GN_THREADS), 0, s, p, ca, cb);
+        return imd_check_launch("groupnorm coeffs (producer statistics)");
+    }
     dim3 grid(gn_chunks(p.B, p.HW, p.C), p.B);
     if (p.dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(gn_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, p);
     else hipLaunchKernelGGL(gn_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, p);

@@ -146,6 +146,9 @@ FUSED_FF_MIN_ROWS = 24576  # below this the 128-row workgroups cannot fill the c
 import os as _os
 FUSED_GN_STATS = _os.environ.get("IMD_FUSED_GN_STATS", "1") != "0"   # 3x3 convs on the halo-patch kernel emit the GroupNorm statistics of their output from the epilogue (A/B switch)
 CFG_PAIR_DEDUP = _os.environ.get("IMD_CFG_PAIR_DEDUP", "1") != "0"   # sampling loop: conv_in + first resnet once for the two identical CFG halves (A/B switch)
+# A/B only (round 6, measured slower -- DESIGN section 6): GroupNorm + SiLU of a ResNet's 3x3 convolutions applied inside the halo-patch kernel while
+# its patch is staged (register-staged form, coefficients from group_norm_coeffs) instead of by a gn_apply launch in front of the LDS-DMA form
+FUSED_GN_CONV = _os.environ.get("IMD_FUSED_GN_CONV", "0") == "1"
 CFG_PAIR_ATTN = _os.environ.get("IMD_CFG_PAIR_ATTN", "1") != "0"     # ... and the first hybrid block up to its self-attention phase (unet.Transformer2D.call_pair_half; A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
@@ -651,6 +654,9 @@ def group_norm_coeffs(x: torch.Tensor, gamma, beta, *, groups=32, eps=1e-5):
     p.partial = part.data_ptr()
     p.B, p.HW, p.C, p.G, p.x_ld, p.y_ld = B, HW, Cc, groups, Cc, Cc
     p.eps, p.silu = eps, 0
+    st = getattr(x, "_imd_gn_stats", None)        # statistics written by the producer of x (see group_norm): no statistics pass
+    if st is not None and st[2] == groups and st[0].shape[0] == B and FUSED_GN_STATS:
+        p.partial, p.nparts = st[0].data_ptr(), st[1]
     L.check(lib.imd_groupnorm_coeffs(C.byref(p), ab[0].data_ptr(), ab[1].data_ptr(), _stream()))
     return ab[0], ab[1]
 

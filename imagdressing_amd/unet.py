@@ -364,6 +364,12 @@ class ResnetBlock:
         temb_slices.append((sd[f"{p}.time_emb_proj.weight"], sd[f"{p}.time_emb_proj.bias"]))
 
     def __call__(self, x, temb_all):
+        if ops.FUSED_GN_CONV and x.shape[2] >= 32 and x.shape[1] >= 8:          # (A/B switch: the 64x64 / 32x32 maps, where the halo-patch kernel is the tuned choice)
+            a, b = ops.group_norm_coeffs(x, self.norm1.weight, self.norm1.bias, groups=self.groups, eps=1e-5)
+            h = self.conv1(x, rowvec=temb_all, rowvec_stride=temb_all.shape[1], rowvec_off=self.temb_off, gn_stats_groups=self.groups, gn=(a, b, True))
+            a, b = ops.group_norm_coeffs(h, self.norm2.weight, self.norm2.bias, groups=self.groups, eps=1e-5)
+            sc = x if self.shortcut is None else self.shortcut(x)
+            return self.conv2(h, res=sc, gn_stats_groups=self.groups, gn=(a, b, True))
         h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, groups=self.groups, eps=1e-5, silu=True)
         # (gn_stats_groups: where the conv runs on the halo-patch kernel its epilogue also emits the GroupNorm statistics of its
         # output, and the next group_norm of that tensor -- norm2 here, the following block's norm after conv2 -- skips its own pass)
