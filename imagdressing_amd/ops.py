@@ -26,7 +26,15 @@ def _code(t: torch.Tensor, name: str = "tensor") -> int:
         raise L.ImdError(f"{name}: expected a bfloat16 or float16 tensor, got {t.dtype}") from None
 
 
+try:        # the raw handle of torch's current stream without building a torch.cuda.Stream object per call (6 x ~4 us per processor call)
+    _raw_stream, _cur_dev = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:      # (a torch build without the private entry points)
+    _raw_stream = _cur_dev = None
+
+
 def _stream() -> int:
+    if _raw_stream is not None:
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -67,7 +75,7 @@ _ws: Dict[Tuple, torch.Tensor] = {}
 def workspace(tag: str, shape: Sequence[int], dtype, device, init=None) -> torch.Tensor:
     """Persistent scratch keyed by (tag, shape, dtype, device, CURRENT STREAM): launches on one stream are ordered, so one buffer
     per stream is race-free; two pipelines driven on two streams of one process get separate buffers instead of silently sharing."""
-    key = (tag, tuple(shape), dtype, str(device), _stream())
+    key = (tag, tuple(shape), dtype, device.type, device.index, _stream()) if isinstance(device, torch.device) else (tag, tuple(shape), dtype, str(device), None, _stream())
     t = _ws.get(key)
     if t is None:
         t = torch.zeros(tuple(shape), dtype=dtype, device=device)
@@ -97,6 +105,7 @@ def clear_workspaces(stream: Optional[int] = None):
     when it releases its side stream / captured step graph, so that a later stream that happens to reuse the handle value cannot pick up
     a buffer the caching allocator still associates with the old stream, and nothing accumulates per stream for the process lifetime."""
     if stream is None:
+        _CFG_DECISIONS.clear()
         _ws.clear()
         _splitk_ws.clear()
         _splitk_cnt.clear()
@@ -154,6 +163,7 @@ FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 chann
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
 GEMM_EVENT_HOOK = None     # tools/insitu_conv.py sets this to a dict: every conv_gemm launch is bracketed by HIP events, keyed by (shape key, cfg, split)
 _GEMM_TABLE = None
+_CFG_DECISIONS: Dict[Tuple, Tuple[int, int]] = {}      # conv_gemm: problem description -> (tile config, K slices), see there
 
 # ---- per-call tuning (include/imagdressing_hip.h: IMD_TUNING_PER_CALL) ----------------------------------------------------------------
 # imd_set_tuning() is process-wide.  Inside ``with tuning_scope(...)`` every params block built by this module carries the scope's choice in
@@ -301,6 +311,17 @@ def conv_gemm(
     if GEMM_TRACE is not None:
         GEMM_TRACE.append(dict(M=M, N=N, K=K, Cin=Cin, taps=taps, Hin=Hin, Win=Win, Hout=Hout, Wout=Wout, stride=stride,
                                ups=int(ups), splittable=splittable, dtype=str(dt)))
+    # (round 6) the (tile config, K slices) decision of a call site is a pure function of the problem description: remembered per description, so
+    # that a repeated layer pays neither the table key formatting nor the library's *_supported queries again (~5 of the ~75 us a processor call
+    # costs on the host at the small levels).  Dropped with the tuning table (IMD_GEMM_TUNING / _GEMM_TABLE reset) and by clear_workspaces().
+    dkey = None
+    if cfg == -1 and split_k == 0 and GEMM_TRACE is None:
+        hk = None if heads is None else (heads["C"], heads["H"], heads["D"], tuple((t is None, kind, DP, Ltok) for t, kind, DP, Ltok, _ in heads["dests"]))
+        dkey = (M, N, K, Cin, taps, stride, int(ups), Hin, Win, Hout, Wout, p.x_pix_stride, p.res_ld, p.out_ld, act, int(out_f32), int(pad_br_only), p.dtype,
+                rowvec is None, res is None, bias is None, hk, PATCH_CONV, id(_GEMM_TABLE))
+        hit = _CFG_DECISIONS.get(dkey)
+        if hit is not None:
+            cfg, split_k = hit
     if cfg == -1 and split_k == 0:
         # 3x3 convs are keyed WITH their output map as well (round 3): the same (M, N, K) occurs for different maps -- 2 images of
         # 20x16 and 8 images of 10x8 are both 640 rows -- and the halo-patch kernel only takes maps at least 16 wide
@@ -339,6 +360,8 @@ def conv_gemm(
         cfg = 5
     if split_k == 0:        # auto: K slices only where the tile grid cannot fill the chip
         split_k = 1 if not splittable else lib.imd_conv_gemm_auto_split(M, N, K, cfg)
+    if dkey is not None and len(_CFG_DECISIONS) < 4096:
+        _CFG_DECISIONS[dkey] = (cfg, split_k)
     p.split_k = split_k
     if split_k > 1:
         p.splitk_ws = splitk_workspace(split_k * M * N, x.device).data_ptr()
