@@ -427,13 +427,8 @@ template <bool F16, int D, int QW, int MINW, int KB = 2, bool SPEC = false, int 
 int launch_attn(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
     constexpr int lds = 2 * C::BUF;
-    static bool attr_set = false;
     auto kern = attn_kernel<F16, D, QW, MINW, KB, SPEC, SCHED>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return imd_set_error("attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), lds, "attention")) return rc_attr;
     const int rows = 4 * QW * 32;
     dim3 grid((p.N + rows - 1) / rows, p.H, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);

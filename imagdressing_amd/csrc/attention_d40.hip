@@ -980,17 +980,12 @@ __global__ __launch_bounds__((VAR & 32768) ? 512 : 256, 2) void attn40_kernel(co
 
 template <bool F16, int THR, int VAR>
 int launch_attn40(const AttnParams& p, hipStream_t s) {
-    static bool attr_set = false;
     auto kern = attn40_kernel<F16, THR, VAR>;
     constexpr int NW = (VAR & 32768) ? 8 : 4;
     constexpr int PARKB = NW * ((VAR & 8192) ? PARK_T : PARK) / 4;
     constexpr int LDS_BYTES = (VAR & 512) ? 100 * 1024 : (VAR & 128) ? NRING * BUF_D + PARKB + 1024 : 2 * BUF + PARKB;
     static_assert(!(VAR & 1048576) || LDS_BYTES >= PJ_LDS, "the out-projection's chunk buffers must fit the loop's LDS");
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return imd_set_error("attention(d=40): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), LDS_BYTES, "attention(d=40)")) return rc_attr;
     dim3 grid((p.N + NW * 64 - 1) / (NW * 64), p.H, p.B);
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), LDS_BYTES, s, p);
     return imd_check_launch("attention(d=40)");

@@ -370,13 +370,8 @@ int imd_launch_attention_fp8(const AttnParams& p, int eq, int ek, int ev, hipStr
     if (p.kv1_bdiv <= 0 || (p.k2 && p.kv2_bdiv <= 0) || p.causal) return imd_set_error("attention_fp8: bad kv divisors / causal unsupported");
     if (eq + ek < 0 || eq + ek > 8) return imd_set_error("attention_fp8: eq + ek must be in [0, 8] (the pad slots hold 2^(eq+ek) in e4m3)");
     const bool h = p.dtype == IMD_DTYPE_F16;
-    static bool attr_set[2] = {false, false};
     const void* kern = h ? reinterpret_cast<const void*>(attn40_fp8_kernel<true>) : reinterpret_cast<const void*>(attn40_fp8_kernel<false>);
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) return imd_set_error("attention_fp8: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(kern, LDS_BYTES, "attention_fp8")) return rc_attr;
     dim3 grid((p.N + 255) / 256, p.H, p.B);
     if (h) hipLaunchKernelGGL(attn40_fp8_kernel<true>, grid, dim3(256), LDS_BYTES, s, p, eq, ek, ev);
     else hipLaunchKernelGGL(attn40_fp8_kernel<false>, grid, dim3(256), LDS_BYTES, s, p, eq, ek, ev);

@@ -1,4 +1,6 @@
 // C-ABI entry points of libimagdressing_hip.so (see include/imagdressing_hip.h).
+#include <atomic>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -28,6 +30,44 @@ int imd_check_launch(const char* what) {
 #define IMD_REQUIRE_SIZE(p, what) IMD_REQUIRE((p)->struct_bytes == sizeof(*(p)), \
     "%s: parameter block is %u bytes in the caller's view, this library (ABI v%d) expects %zu: the binding mirrors another version of include/imagdressing_hip.h (set struct_bytes = sizeof(struct) after zero-initialising it)", \
     what, (unsigned)(p)->struct_bytes, IMD_ABI_VERSION, sizeof(*(p)))
+
+// ---- per-device launcher state (see imd_kernels.h) ----
+namespace {
+struct LdsAttrEnt { const void* kern; int dev; };
+constexpr int kMaxLdsAttr = 512;
+LdsAttrEnt g_lds_attr[kMaxLdsAttr];
+std::atomic<int> g_lds_attr_n{0};
+std::mutex g_lds_attr_mu;
+int g_cu8[64] = {};
+}  // namespace
+
+int imd_lds_attr(const void* kern, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return imd_set_error("%s: cannot identify the current device", what);
+    const int n = g_lds_attr_n.load(std::memory_order_acquire);
+    for (int i = 0; i < n; ++i)
+        if (g_lds_attr[i].kern == kern && g_lds_attr[i].dev == dev) return 0;
+    std::lock_guard<std::mutex> lock(g_lds_attr_mu);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
+    const int m = g_lds_attr_n.load(std::memory_order_relaxed);
+    if (m < kMaxLdsAttr) {                 // (a full table only means the attribute is set again on later launches)
+        g_lds_attr[m] = LdsAttrEnt{kern, dev};
+        g_lds_attr_n.store(m + 1, std::memory_order_release);
+    }
+    return 0;
+}
+
+int imd_cu_count8() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+    if (g_cu8[dev] == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+        g_cu8[dev] = cus / 8 * 8 < 8 ? 8 : cus / 8 * 8;
+    }
+    return g_cu8[dev];
+}
 
 extern "C" {
 
@@ -150,6 +190,7 @@ int imd_conv_patch4_supported(const imd_conv_gemm_params* p) { return query(p, s
 int imd_conv_img_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_conv_img_supported)); }
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return sized(p) ? imd_conv_patch_stats_parts_of(*p) : 0; }
 int imd_conv_gemm_stats_parts(const imd_conv_gemm_params* p, int cfg) { return sized(p) ? imd_conv_gemm_stats_parts_of(*p, cfg) : 0; }
+int imd_conv_gemm_gn_out_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_gemm_gn_out_supported_of(*p, -1)) ? 1 : 0; }
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_gemm_dma_supported)); }
 
 int imd_row_linear_supported(const imd_conv_gemm_params* p) { return (sized(p) && (imd_row_linear_supported(*p) || imd_row_linear_k640_supported(*p) || imd_row_linear_k1280_supported(*p) || imd_row_qkv_supported(*p))) ? 1 : 0; }

@@ -399,6 +399,98 @@ __global__ __launch_bounds__(FS_THREADS) void splitk_finish_stats_kernel(const C
     }
 }
 
+// ---- finish launch with GroupNorm (+ SiLU) of the output (round 6; imd_conv_gemm_params.gn_out_*) ----
+// One workgroup = all pixels of one (image, group): cpg channels in units of 4 (N / G = 40 or 20 at the 16x16 / 8x8 levels), HW * cpg / 4 units
+// spread over 256 threads, at most FG_MAXU per thread, kept in registers between the two phases:
+//   phase 1  unit value = sum of the K slices (ascending, like splitk_finish_kernel) + bias + per-batch vector (the epilogue's first addition;
+//            residual / scale / activation are refused by the launcher: ResnetBlock2D.conv1 has none), rounded to the element type -- the
+//            value the separate GroupNorm launch would read back -- and its (sum, sum of squares) in fp32;
+//   fold     lane-wise partials -> LDS -> thread 0 sums the 256 entries in ascending order (deterministic) -> mean, rstd;
+//   phase 2  y = act(r * gamma rstd + (beta - mean gamma rstd)) exactly as gn_apply_kernel forms it, packed, stored (8 bytes per unit).
+constexpr int FG_THREADS = 256, FG_MAXU = 12;
+
+template <bool F16>
+__global__ __launch_bounds__(FG_THREADS) void splitk_finish_gn_kernel(const ConvGemmParams p) {
+    using E = El<F16>;
+    __shared__ float red_s[FG_THREADS], red_q[FG_THREADS];
+    __shared__ float s_stat[2];
+    const int HWo = p.Hout * p.Wout;
+    const int G = p.gn_out_groups, cpg = p.N / G, upr = cpg / 4;          // units (4 channels) per pixel row of this group
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int units = HWo * upr;
+    const size_t slab = (size_t)p.M * p.N;
+    float v[FG_MAXU][4];
+    float S = 0.f, Q = 0.f;
+#pragma unroll
+    for (int i = 0; i < FG_MAXU; ++i) {
+        const int u = tid + i * FG_THREADS;
+        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        if (u < units) {
+            const int row = u / upr, n = g * cpg + (u - row * upr) * 4;
+            const int m = b * HWo + row;
+            for (int sl = 0; sl < p.split_k; ++sl) {
+                const float4 a = *reinterpret_cast<const float4*>(p.splitk_ws + sl * slab + (size_t)m * p.N + n);
+                v[i][0] += a.x; v[i][1] += a.y; v[i][2] += a.z; v[i][3] += a.w;
+            }
+            float4 add = make_float4(0, 0, 0, 0);
+            if (p.bias) add = *reinterpret_cast<const float4*>(p.bias + n);
+            if (p.rowvec) {
+                const float4 r = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_stride + n);
+                add.x += r.x; add.y += r.y; add.z += r.z; add.w += r.w;
+            }
+            v[i][0] += add.x; v[i][1] += add.y; v[i][2] += add.z; v[i][3] += add.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = E::tof(E::fromf(v[i][e]));
+                v[i][e] = r;
+                S += r; Q += r * r;
+            }
+        }
+    }
+    red_s[tid] = S; red_q[tid] = Q;
+    __syncthreads();
+    if (tid == 0) {
+        float St = 0.f, Qt = 0.f;
+        for (int k = 0; k < FG_THREADS; ++k) { St += red_s[k]; Qt += red_q[k]; }
+        const float cnt = (float)HWo * (float)cpg;
+        const float mean = St / cnt;
+        const float var = fmaxf(Qt / cnt - mean * mean, 0.f);
+        s_stat[0] = mean;
+        s_stat[1] = rsqrtf(var + p.gn_out_eps);
+    }
+    __syncthreads();
+    const float mean = s_stat[0], rstd = s_stat[1];
+    bf16_t* out = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+    for (int i = 0; i < FG_MAXU; ++i) {
+        const int u = tid + i * FG_THREADS;
+        if (u >= units) continue;
+        const int row = u / upr, n = g * cpg + (u - row * upr) * 4;
+        const int m = b * HWo + row;
+        const float4 ga4 = *reinterpret_cast<const float4*>(p.gn_out_gamma + n), be4 = *reinterpret_cast<const float4*>(p.gn_out_beta + n);
+        const float gam[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, bet[4] = {be4.x, be4.y, be4.z, be4.w};
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float ga = gam[e] * rstd;
+            const float sh = bet[e] - mean * ga;
+            y[e] = v[i][e] * ga + sh;
+            if (p.gn_out_silu) y[e] = silu_f(y[e]);
+        }
+        *reinterpret_cast<uint2*>(out + (size_t)m * p.out_ld + n) = make_uint2(E::pack2(y[0], y[1]), E::pack2(y[2], y[3]));
+    }
+}
+
+bool splitk_gn_out_supported(const ConvGemmParams& p) {
+    if (p.gn_out_gamma == nullptr || p.gn_out_beta == nullptr || p.split_k <= 1 || p.splitk_counters != nullptr || p.mode != OUT_ROWMAJOR || p.out_f32 ||
+        p.act != ACT_NONE || p.res != nullptr || p.out_scale != 1.0f || p.gn_stats_out != nullptr) return false;
+    const int G = p.gn_out_groups, HW = p.Hout * p.Wout;
+    if (G <= 0 || G > 65535 || p.N % G || HW <= 0 || p.M % HW) return false;
+    const int cpg = p.N / G;
+    if ((cpg % 4) || (p.out_ld % 4) || (p.rowvec && (p.rowvec_stride % 4))) return false;
+    return (long)HW * (cpg / 4) <= (long)FG_THREADS * FG_MAXU;
+}
+
 // statistic partials per image the finish launch writes (0: this problem cannot take the statistics form)
 int splitk_stats_parts_of(const ConvGemmParams& p) {
     if (p.split_k <= 1 || p.splitk_counters != nullptr || p.mode != OUT_ROWMAJOR || p.out_f32 || p.act == ACT_GEGLU || (p.N % 8) ||
@@ -411,6 +503,15 @@ int splitk_stats_parts_of(const ConvGemmParams& p) {
 // the second launch of a K-sliced problem: sum the slabs, run the epilogue (+ GroupNorm statistics of the output when asked for)
 int launch_splitk_finish(const ConvGemmParams& p, hipStream_t s, const char* what) {
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if (p.gn_out_gamma != nullptr) {
+        if (!splitk_gn_out_supported(p))
+            return imd_set_error("%s: gn_out_* on a problem whose finish launch cannot normalise (ask imd_conv_gemm_gn_out_supported(): K slices with a separate "
+                                 "finish, row-major 16-bit output, no residual / activation / scale, 4 | N / groups, H W N / groups <= %d)", what, 4 * FG_THREADS * FG_MAXU);
+        const int B = p.M / (p.Hout * p.Wout);
+        if (h) hipLaunchKernelGGL(splitk_finish_gn_kernel<true>, dim3((unsigned)p.gn_out_groups, (unsigned)B), dim3(FG_THREADS), 0, s, p);
+        else hipLaunchKernelGGL(splitk_finish_gn_kernel<false>, dim3((unsigned)p.gn_out_groups, (unsigned)B), dim3(FG_THREADS), 0, s, p);
+        return imd_check_launch(what);
+    }
     if (p.gn_stats_out != nullptr) {
         const int nparts = splitk_stats_parts_of(p);
         if (nparts == 0) return imd_set_error("%s: gn_stats_out on a K-sliced problem that cannot produce the statistics", what);
@@ -431,13 +532,8 @@ template <bool F16, int BM, int BN, int BK, int WM, int WN, int DEPTH = 2>
 int launch_cfg(const ConvGemmParams& p, hipStream_t s) {
     static_assert(DEPTH == 2 || DEPTH == 4, "pipeline depth");
     constexpr int lds = TileCfg<BM, BN, BK, WM>::LDS;
-    static bool attr_set = false;
     auto kern = conv_gemm_kernel<F16, BM, BN, BK, WM, WN, DEPTH>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return imd_set_error("conv_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), lds, "conv_gemm")) return rc_attr;
     const long mt = (p.M + BM - 1) / BM, nt = (p.N + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(WM * WN * 64), lds, s, p);
     int rc = imd_check_launch("conv_gemm");
@@ -491,6 +587,14 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
     return (cfg == 5 || cfg == 29) ? imd_conv_patch_stats_parts_of(p) : 0;
+}
+
+// can the finish launch of `p` (tile config `cfg`) normalise its output (gn_out_*)?  The in-kernel K-slice sum (splitk_counters) is simply not used then.
+bool imd_conv_gemm_gn_out_supported_of(const ConvGemmParams& p_in, int cfg) {
+    ConvGemmParams p = p_in;
+    (void)cfg;
+    p.splitk_counters = nullptr;
+    return splitk_gn_out_supported(p);
 }
 
 int imd_conv_gemm_choose_cfg(int M, int N) {
@@ -573,6 +677,13 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
         return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 / 22 / 23 / 29 without K slices or any K-sliced launch with a separate finish, a row-major 16-bit "
                              "output and 1 <= groups <= 64 with N %% groups == 0 and N / groups >= 8 (got cfg=%d split_k=%d groups=%d N=%d); ask "
                              "imd_conv_gemm_stats_parts() first", cfg, p.split_k, p.gn_stats_groups, p.N);
+    // GroupNorm of the output inside the finish launch (ABI v9): only a K-sliced problem with a separate finish has one -- anything else is an
+    // ERROR (a launch that silently skipped the normalisation would hand the caller a tensor it believes normalised)
+    if (p.gn_out_gamma != nullptr && !imd_conv_gemm_gn_out_supported_of(p, cfg))
+        return imd_set_error("conv_gemm: gn_out_* needs K slices with a separate finish launch, a row-major 16-bit output without residual / activation / scale / "
+                             "gn_stats_out, 4 | N / groups and H W N / groups <= %d (got cfg=%d split_k=%d groups=%d N=%d); ask imd_conv_gemm_gn_out_supported() first",
+                             4 * FG_THREADS * FG_MAXU, cfg, p.split_k, p.gn_out_groups, p.N);
+    if (p.gn_out_gamma != nullptr) p.splitk_counters = nullptr;
     if (p.splitk_counters != nullptr) {          // one counter per output tile; larger grids keep the two-launch path
         int bm = 128, bn = 128;
         if (cfg == 5) { bm = 128; bn = 128; } else tile_dims(cfg, &bm, &bn);

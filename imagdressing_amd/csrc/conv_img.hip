@@ -243,15 +243,10 @@ __global__ __launch_bounds__(IMG * 64, 1) void conv3x3_img_kernel(const ConvGemm
 template <int IMG, int NPB>
 int launch_img(const ConvGemmParams& p, hipStream_t s) {
     using G = CI<IMG, NPB>;
-    static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = h ? conv3x3_img_kernel<true, IMG, NPB> : conv3x3_img_kernel<false, IMG, NPB>;
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        if (e != hipSuccess) return imd_set_error("conv_img: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), G::LDS, "conv_img")) return rc_attr;
     const int B = p.M / (p.Hout * p.Wout);
     const long blocks = (long)p.split_k * (p.N / CI_BN) * ((B + IMG - 1) / IMG);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(IMG * 64), G::LDS, s, p);

@@ -549,15 +549,10 @@ bool imd_conv_patch64_supported(const ConvGemmParams& p) {
 
 int imd_launch_conv_patch64(const ConvGemmParams& p, hipStream_t s) {
     if (!imd_conv_patch64_supported(p)) return imd_set_error("conv_patch (128-byte rows): unsupported problem (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 64 == 0, operands < 2 GiB, no fused GroupNorm)");
-    static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = h ? conv3x3_patch_kernel<true, true, 64> : conv3x3_patch_kernel<false, true, 64>;
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PD<64>::LDS);
-        if (e != hipSuccess) return imd_set_error("conv_patch: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), PD<64>::LDS, "conv_patch")) return rc_attr;
     const int B = p.M / (p.Hout * p.Wout);
     const long blocks = (long)B * ((p.Hout + TH - 1) / TH) * ((p.Wout + TW - 1) / TW) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PD<64>::LDS, s, p);
@@ -566,7 +561,6 @@ int imd_launch_conv_patch64(const ConvGemmParams& p, hipStream_t s) {
 
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
     if (!imd_conv_patch_supported(p)) return imd_set_error("conv_patch: unsupported geometry (needs 3x3 stride 1, H >= 8, W >= 16, Cin %% 32 == 0)");
-    static bool attr_set[2][2] = {{false, false}, {false, false}};
     const bool h = p.dtype == IMD_DTYPE_F16;
     // LDS-DMA staging of both operands unless the fused GroupNorm prologue (values needed in registers) is asked for, or tuning knob 2
     // bit 9 selects the round-1/2 register-staged form (A/B)
@@ -576,11 +570,7 @@ int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s) {
     const kern_t kern = dma ? (h ? conv3x3_patch_kernel<true, true> : conv3x3_patch_kernel<false, true>)
                             : (h ? conv3x3_patch_kernel<true, false> : conv3x3_patch_kernel<false, false>);
     const int lds = dma ? PATCH_DMA_LDS : PATCH_LDS;
-    if (!attr_set[h][dma]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return imd_set_error("conv_patch: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h][dma] = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), lds, "conv_patch")) return rc_attr;
     const int B = p.M / (p.Hout * p.Wout);
     const long blocks = (long)B * ((p.Hout + TH - 1) / TH) * ((p.Wout + TW - 1) / TW) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), lds, s, p);

@@ -224,15 +224,10 @@ int imd_launch_conv_patch2(const ConvGemmParams& p_in, hipStream_t s) {
     ConvGemmParams p = p_in;
     p.splitk_counters = nullptr;               // K slices are summed by the shared finish launch
     p.gn_stats_out = nullptr;
-    static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = h ? conv3x3_patch2_kernel<true> : conv3x3_patch2_kernel<false>;
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PATCH2_LDS);
-        if (e != hipSuccess) return imd_set_error("conv_patch2: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), PATCH2_LDS, "conv_patch2")) return rc_attr;
     const int B = p.M / (p.Hout * p.Wout);
     const long blocks = (long)B * ((p.Hout + T2H - 1) / T2H) * ((p.Wout + T2W - 1) / T2W) * ((p.N + BN2 - 1) / BN2);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(256), PATCH2_LDS, s, p);

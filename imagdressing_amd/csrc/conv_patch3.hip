@@ -313,15 +313,10 @@ static int launch_patch3(const ConvGemmParams& p_in, hipStream_t s, const char* 
     if (p.split_k > 1) p.gn_stats_out = nullptr;      // (K slices: the statistics come from the finish launch; the dispatcher validated the request)
     if (!patch3_geometry(p, T3<NW>::TH))
         return imd_set_error("%s: unsupported geometry (needs 3x3 stride 1, H >= %d, W >= 16, Cin %% 32 == 0, row-major output, operands < 2 GiB)", what, T3<NW>::TH);
-    static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = h ? conv3x3_patch3_kernel<true, NW> : conv3x3_patch3_kernel<false, NW>;
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T3<NW>::LDS);
-        if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), T3<NW>::LDS, "%s")) return rc_attr;
     const int B = p.M / (p.Hout * p.Wout);
     const long blocks = (long)B * ((p.Hout + T3<NW>::TH - 1) / T3<NW>::TH) * ((p.Wout + T3W - 1) / T3W) * ((p.N + BN3 - 1) / BN3);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.split_k), dim3(NW * 64), T3<NW>::LDS, s, p);

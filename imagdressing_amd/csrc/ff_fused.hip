@@ -273,14 +273,9 @@ int imd_launch_ff_geglu(const imd_ff_params& p, hipStream_t s) {
     if (((size_t)(p.M - 1) * p.x_ld + FF_C) * 2 >= 0xffffffffull || ((size_t)(p.M - 1) * p.out_ld + FF_C) * 2 >= 0xffffffffull)
         return imd_set_error("ff_geglu: operand larger than 4 GiB");
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("ff_geglu: unknown dtype %d", p.dtype);
-    static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     const void* kern = h ? reinterpret_cast<const void*>(ff_geglu320_kernel<true>) : reinterpret_cast<const void*>(ff_geglu320_kernel<false>);
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LDS);
-        if (e != hipSuccess) return imd_set_error("ff_geglu: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(kern, FF_LDS, "ff_geglu")) return rc_attr;
     const dim3 grid((unsigned)((p.M + 127) / 128));
     if (h) hipLaunchKernelGGL(ff_geglu320_kernel<true>, grid, dim3(512), FF_LDS, s, p);
     else hipLaunchKernelGGL(ff_geglu320_kernel<false>, grid, dim3(512), FF_LDS, s, p);

@@ -355,17 +355,12 @@ bool imd_conv_dma_supported(const ConvGemmParams& p) {       // tile config 18: 
 
 template <bool GATHER, int NST, int BK = 32>
 static int launch_dma128(const ConvGemmParams& p, hipStream_t s, const char* what) {
-    static bool attr_set[2] = {false, false};
     constexpr int LDS = NST * (G1_BM + G1_BN) * BK * 2;        // BK = 32: 49152 (three stages) | 65536 (four); BK = 64: 65536 (two) | 98304 (three)
     static_assert(LDS >= G1_EROWS * G1_CLD * 4, "epilogue tile must fit");
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = h ? gemm_dma128_kernel<true, GATHER, NST, BK> : gemm_dma128_kernel<false, GATHER, NST, BK>;
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), LDS, "%s")) return rc_attr;
     const long mt = (p.M + G1_BM - 1) / G1_BM, nt = (p.N + G1_BN - 1) / G1_BN;
     hipLaunchKernelGGL(kern, dim3((unsigned)(mt * nt), (unsigned)p.split_k), dim3(256), LDS, s, p);
     return imd_check_launch(what);
@@ -403,14 +398,9 @@ bool imd_gemm_dma_supported(const ConvGemmParams& p) {
 
 int imd_launch_gemm_dma(const ConvGemmParams& p, hipStream_t s) {      // p: validated and completed (x_bytes, w_bytes, flags) by imd_launch_conv_gemm
     if (!imd_gemm_dma_supported(p)) return imd_set_error("gemm_dma: needs a plain linear layer with K %% 64 == 0 and no K split (got K=%d taps=%d split=%d)", p.K, p.taps, p.split_k);
-    static bool attr_set[2] = {false, false};
     const bool h = p.dtype == IMD_DTYPE_F16;
     const void* kern = h ? reinterpret_cast<const void*>(gemm_dma_kernel<true>) : reinterpret_cast<const void*>(gemm_dma_kernel<false>);
-    if (!attr_set[h]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, GD_LDS);
-        if (e != hipSuccess) return imd_set_error("gemm_dma: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set[h] = true;
-    }
+    if (int rc_attr = imd_lds_attr(kern, GD_LDS, "gemm_dma")) return rc_attr;
     const long mt = (p.M + GD_BM - 1) / GD_BM, nt = (p.N + GD_BN - 1) / GD_BN;
     if (h) hipLaunchKernelGGL(gemm_dma_kernel<true>, dim3((unsigned)(mt * nt)), dim3(512), GD_LDS, s, p);
     else hipLaunchKernelGGL(gemm_dma_kernel<false>, dim3((unsigned)(mt * nt)), dim3(512), GD_LDS, s, p);

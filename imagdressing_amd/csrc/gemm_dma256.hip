@@ -407,30 +407,17 @@ __global__ __launch_bounds__((G2Waves<BM>::NCW + G2Waves<BM>::NPROD) * 64, 3) vo
 
 template <int BM, int BN, int NST, bool PRE, bool RES>
 int launch_dma256_v(const ConvGemmParams& p, bool persistent, hipStream_t s, const char* what) {
-    // per DEVICE (a process may drive several GPUs): the 160 KB dynamic-LDS attribute is per device and the persistent grid is sized from
-    // the current device's CU count
-    constexpr int MAXDEV = 16;
-    static bool attr_set[MAXDEV][2] = {};
-    static int n_cu_of[MAXDEV] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return imd_set_error("%s: cannot identify the current device", what);
     constexpr int LDS = NST * (BM + BN) * G2_ROWB + (BM / 32) * 2048;      // ring + the consumer waves' 2 KB store-transpose areas
     constexpr int WG_PER_CU = BM >= 192 ? 1 : 2;
     static_assert(LDS * WG_PER_CU <= 160 * 1024, "ring + transpose areas must fit the CU's LDS");
     const bool h = p.dtype == IMD_DTYPE_F16;
     typedef void (*kern_t)(const ConvGemmParams);
     const kern_t kern = h ? gemm_dma256_kernel<true, BM, BN, NST, PRE, RES> : gemm_dma256_kernel<false, BM, BN, NST, PRE, RES>;
-    if (!attr_set[dev][h]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return imd_set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
-        attr_set[dev][h] = true;
-    }
-    if (n_cu_of[dev] == 0) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return imd_set_error("%s: cannot query the device", what);
-        n_cu_of[dev] = cus / 8 * 8 < 8 ? 8 : cus / 8 * 8;          // a multiple of 8: a block's items stay on its XCD's share of the tile order
-    }
-    const int n_cu = n_cu_of[dev];
+    // per DEVICE (a process may drive several GPUs): the 160 KB dynamic-LDS attribute and the CU count that sizes the persistent grid
+    // (a multiple of 8: a block's items stay on its XCD's share of the tile order)
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), LDS, what)) return rc_attr;
+    const int n_cu = imd_cu_count8();
+    if (n_cu < 0) return imd_set_error("%s: cannot query the device", what);
     const long items = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.split_k;
     const long slots = (long)n_cu * WG_PER_CU;
     const long grid = persistent ? (items < slots ? items : slots) : items;

@@ -20,6 +20,11 @@ enum { OUT_ROWMAJOR = IMD_OUT_ROWMAJOR, OUT_HEADS = IMD_OUT_HEADS };
 // error plumbing (thread-local message, surfaced by imd_last_error())
 int imd_set_error(const char* fmt, ...);
 int imd_check_launch(const char* what);
+// hipFuncAttributeMaxDynamicSharedMemorySize of `kern` on the CURRENT device, set once per (device, kernel): the attribute is per device, a
+// process may drive several (round-5 advisor finding: a per-process flag left the second device's first launch without it).  0 = ok.
+int imd_lds_attr(const void* kern, int bytes, const char* what);
+// CU count of the current device rounded down to a multiple of 8 (one share per XCD), at least 8; -1 on error (persistent grids)
+int imd_cu_count8();
 
 int imd_conv_gemm_choose_cfg(int M, int N);
 int imd_conv_gemm_choose_split(int M, int N, int K, int cfg);
@@ -39,6 +44,7 @@ bool imd_conv_img_supported(const ConvGemmParams& p);         // conv_img.hip: w
 int imd_launch_conv_img(const ConvGemmParams& p, hipStream_t s);
 int imd_conv_patch_stats_parts_of(const ConvGemmParams& p);
 int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p, int cfg);
+bool imd_conv_gemm_gn_out_supported_of(const ConvGemmParams& p, int cfg);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
 bool imd_row_linear_supported(const ConvGemmParams& p);                                    // row_linear.hip
 int imd_launch_row_linear(const ConvGemmParams& p, int ln, float ln_eps, hipStream_t s);

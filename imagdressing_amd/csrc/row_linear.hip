@@ -271,13 +271,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
 
 template <bool F16, int NC, bool LN, bool DIRECT>
 int launch_rl_d(const ConvGemmParams& p, float eps, hipStream_t s) {
-    static bool attr_set = false;
     auto kern = row_linear_kernel<F16, NC, LN, DIRECT>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RL_LDS_TOTAL);
-        if (e != hipSuccess) return imd_set_error("row_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), RL_LDS_TOTAL, "row_linear")) return rc_attr;
     hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + RL_BM - 1) / RL_BM)), dim3(512), RL_LDS_TOTAL, s, p, eps);
     return imd_check_launch("row_linear");
 }

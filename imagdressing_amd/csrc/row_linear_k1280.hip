@@ -251,13 +251,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
 
 template <bool F16, bool LN>
 int launch_r12(const ConvGemmParams& p, float eps, hipStream_t s) {
-    static bool attr_set = false;
     auto kern = row_linear_k1280_kernel<F16, LN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R12_LDS);
-        if (e != hipSuccess) return imd_set_error("row_linear_k1280: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), R12_LDS, "row_linear_k1280")) return rc_attr;
     const unsigned grid = (unsigned)((((p.M + 63) / 64 + 7) / 8) * 8 * (p.N / R12_NG));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), R12_LDS, s, p, eps);
     return imd_check_launch("row_linear_k1280");

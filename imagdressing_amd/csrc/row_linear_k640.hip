@@ -225,13 +225,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
 
 template <bool F16, bool LN>
 int launch_r6(const ConvGemmParams& p, float eps, hipStream_t s) {
-    static bool attr_set = false;
     auto kern = row_linear_k640_kernel<F16, LN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R6_LDS);
-        if (e != hipSuccess) return imd_set_error("row_linear_k640: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), R6_LDS, "row_linear_k640")) return rc_attr;
     const unsigned grid = (unsigned)((((p.M + 127) / 128 + 7) / 8) * 8 * (p.N / R6_NG));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), R6_LDS, s, p, eps);
     return imd_check_launch("row_linear_k640");

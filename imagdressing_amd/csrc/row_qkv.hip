@@ -181,13 +181,8 @@ __global__ __launch_bounds__(512, 1) void row_qkv_kernel(const ConvGemmParams p,
 
 template <bool F16, bool LN>
 int launch_rq(const ConvGemmParams& p, float eps, hipStream_t s) {
-    static bool attr_set = false;
     auto kern = row_qkv_kernel<F16, LN>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, RQ_LDS);
-        if (e != hipSuccess) return imd_set_error("row_qkv: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), RQ_LDS, "row_qkv")) return rc_attr;
     hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + 127) / 128)), dim3(512), RQ_LDS, s, p, eps);
     return imd_check_launch("row_qkv");
 }

@@ -158,6 +158,10 @@ CFG_PAIR_DEDUP = _os.environ.get("IMD_CFG_PAIR_DEDUP", "1") != "0"   # sampling 
 # A/B only (round 6, measured slower -- DESIGN section 6): GroupNorm + SiLU of a ResNet's 3x3 convolutions applied inside the halo-patch kernel while
 # its patch is staged (register-staged form, coefficients from group_norm_coeffs) instead of by a gn_apply launch in front of the LDS-DMA form
 FUSED_GN_CONV = _os.environ.get("IMD_FUSED_GN_CONV", "0") == "1"
+# (round 6) ResnetBlock2D.norm2 + SiLU inside the finish launch of a K-sliced conv1 (the 16x16 / 8x8 levels): one launch and one HBM round trip less per block.
+# OPT-IN: correct and tested, measured neutral at the bench batch (592.0 vs 592.6 ms) and 1.1 % SLOWER at batch 1 (350.8 -> 354.9 ms), same box,
+# interleaved twice (profiles/r6h_*): a workgroup per (image, group) reads 160-byte column strips of the fp32 slabs where the plain finish reads whole rows
+FUSED_GN_FINISH = _os.environ.get("IMD_FUSED_GN_FINISH", "0") == "1"
 CFG_PAIR_ATTN = _os.environ.get("IMD_CFG_PAIR_ATTN", "1") != "0"     # ... and the first hybrid block up to its self-attention phase (unet.Transformer2D.call_pair_half; A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
@@ -243,6 +247,7 @@ def conv_gemm(
     act: int = ACT_NONE, out_f32: bool = False,
     heads: Optional[dict] = None, cfg: int = -1, split_k: int = 0,
     gn: Optional[tuple] = None, pad_br_only: bool = False, ln_eps: Optional[float] = None, gn_stats_groups: int = 0,
+    gn_out: Optional[tuple] = None,
 ) -> Optional[torch.Tensor]:
     """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
 
@@ -253,6 +258,9 @@ def conv_gemm(
     ``ln_eps``: LayerNorm WITHOUT affine over the K channels of every row of ``x`` is applied on the fly (row-resident kernel,
     K = 320 and N <= 320 only; fold gamma / beta into ``w`` / ``bias`` with :func:`fold_layernorm_affine`).
     ``gn_stats_groups`` = G: when the launch lands on the halo-patch kernel without K slices, or is K-sliced with a separate finish launch,
+    ``gn_out`` = (gamma, beta, eps, silu, groups): where the problem is K-sliced with a separate finish launch and that launch can own whole
+    (image, group) slabs (``imd_conv_gemm_gn_out_supported``: the 16x16 / 8x8 levels), the finish launch applies GroupNorm (+ SiLU) to its output
+    itself; the returned tensor then carries ``_imd_gn_applied = True`` and holds the NORMALISED values.  Ignored (raw output) everywhere else.
     the epilogue / the finish launch also writes the GroupNorm(G) statistics of the OUTPUT (per-tile / per-pixel-part fp32 partials); they ride on the returned tensor (``_imd_gn_stats``) and the next
     :func:`group_norm` of that tensor skips its statistics pass.  Silently not produced on every other path (FUSED_GN_STATS = False: never).
     """
@@ -367,6 +375,20 @@ def conv_gemm(
         p.splitk_ws = splitk_workspace(split_k * M * N, x.device).data_ptr()
         if SPLITK_IN_KERNEL:
             p.splitk_counters = splitk_counters(x.device).data_ptr()
+    if gn_out is not None and FUSED_GN_FINISH and split_k > 1 and heads is None and not out_f32 and act == ACT_NONE and res is None and out_scale == 1.0:
+        # GroupNorm (+ SiLU) of the OUTPUT inside the finish launch of the K slices (ResnetBlock2D: conv1 -> norm2 -> SiLU): the caller finds
+        # `_imd_gn_applied` on the returned tensor and skips its own group_norm
+        g_gamma, g_beta, g_eps, g_silu, g_groups = gn_out
+        p.gn_out_gamma, p.gn_out_beta = _dev(g_gamma, torch.float32, "gn_out gamma"), _dev(g_beta, torch.float32, "gn_out beta")
+        p.gn_out_eps, p.gn_out_silu, p.gn_out_groups = float(g_eps), int(bool(g_silu)), int(g_groups)
+        if lib.imd_conv_gemm_gn_out_supported(C.byref(p)):
+            p.splitk_counters = None
+            gn_stats_groups = 0
+            L.check(lib.imd_conv_gemm(C.byref(p), cfg, _stream()))
+            out._imd_gn_applied = True
+            return out
+        p.gn_out_gamma = p.gn_out_beta = None
+        p.gn_out_groups = 0
     stats = None
     if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and (cfg in (5, 22, 23, 29) or split_k > 1):
         p.gn_stats_groups = gn_stats_groups
@@ -482,7 +504,7 @@ def ff_geglu_fused(x2d: torch.Tensor, packed: dict, ln_eps: float = 1e-5, out: O
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
                 rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0, gn=None,
-                pad_br_only=False, gn_stats_groups=0) -> torch.Tensor:
+                pad_br_only=False, gn_stats_groups=0, gn_out=None) -> torch.Tensor:
     """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout].  ``pad_br_only``: F.pad(x, (0, 1, 0, 1)) + conv(padding=0) (VAE encoder)."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -491,8 +513,10 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1
     M = B * Ho * Wo
     out = conv_gemm(x, w, M=M, N=Cout, Cin=Cin, taps=taps, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups,
                     bias=bias, rowvec=rowvec, rowvec_stride=rowvec_stride, rowvec_off=rowvec_off, res=res, out_scale=out_scale, act=act,
-                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn, pad_br_only=pad_br_only, gn_stats_groups=gn_stats_groups)
+                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn, pad_br_only=pad_br_only, gn_stats_groups=gn_stats_groups, gn_out=gn_out)
     r = out.view(B, Ho, Wo, -1)
+    if getattr(out, "_imd_gn_applied", False):
+        r._imd_gn_applied = True
     st = getattr(out, "_imd_gn_stats", None)
     if st is not None:
         r._imd_gn_stats = st          # (a view is a new tensor object: carry the producer's GroupNorm statistics over)

@@ -373,8 +373,11 @@ class ResnetBlock:
         h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, groups=self.groups, eps=1e-5, silu=True)
         # (gn_stats_groups: where the conv runs on the halo-patch kernel its epilogue also emits the GroupNorm statistics of its
         # output, and the next group_norm of that tensor -- norm2 here, the following block's norm after conv2 -- skips its own pass)
-        h = self.conv1(h, rowvec=temb_all, rowvec_stride=temb_all.shape[1], rowvec_off=self.temb_off, gn_stats_groups=self.groups)
-        h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, groups=self.groups, eps=1e-5, silu=True)
+        # (gn_out: where conv1 is K-sliced -- the 16x16 / 8x8 levels -- its finish launch applies norm2 + SiLU itself and the raw conv1 output never exists)
+        h = self.conv1(h, rowvec=temb_all, rowvec_stride=temb_all.shape[1], rowvec_off=self.temb_off, gn_stats_groups=self.groups,
+                       gn_out=(self.norm2.weight, self.norm2.bias, 1e-5, True, self.groups))
+        if not getattr(h, "_imd_gn_applied", False):
+            h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, groups=self.groups, eps=1e-5, silu=True)
         sc = x if self.shortcut is None else self.shortcut(x)
         return self.conv2(h, res=sc, gn_stats_groups=self.groups)
 

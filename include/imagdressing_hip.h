@@ -103,6 +103,19 @@ typedef struct imd_conv_gemm_params {
      * conv2 -> the next block's norm). */
     float* gn_stats_out;
     int gn_stats_groups;
+    /* GroupNorm (+ SiLU) of the OUTPUT inside the finish launch of a K-sliced problem (ABI v9; imd_conv_gemm_gn_out_supported()): when
+     * gn_out_gamma is given, `out` receives  act(GroupNorm_G(epilogue(sum of the K slices)))  instead of the epilogue's result -- the tensor
+     * ResnetBlock2D.norm2 + nonlinearity would produce from conv1's output, which nothing else reads (diffusers-0.24 ResnetBlock2D.forward:
+     * conv1 -> + temb -> norm2 -> SiLU -> conv2).  One workgroup owns all pixels of one (image, group), so the statistics are complete in
+     * the launch: the un-normalised tensor never exists in memory and the separate imd_groupnorm launch disappears.  Statistics are those of
+     * the value ROUNDED to the element type (what imd_groupnorm would read back), fp32, fixed summation order.  Needs split_k > 1 without
+     * splitk_counters, a row-major 16-bit output without activation / GEGLU, N % groups == 0 with 4 | N / groups, and
+     * Hout * Wout * (N / groups) <= 12288 (the 16x16 and 8x8 levels); gn_stats_out must be NULL (there is nothing left to normalise). */
+    const float* gn_out_gamma; /* [N] or NULL */
+    const float* gn_out_beta;  /* [N] */
+    float gn_out_eps;
+    int gn_out_silu;
+    int gn_out_groups;
 } imd_conv_gemm_params;
 #define IMD_SPLITK_COUNTERS 16384
 
@@ -261,6 +274,8 @@ int imd_attention_fp8(const imd_attn_params* p, int eq, int ek, int ev, void* st
  *         at position 32 ((k >> 3) & 1) + 8 ((k >> 4) & 3) + (k & 7) (the order the kernel's packed P comes out in). */
 int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long count, int LP, int exp2_scale, float pad_val, int dtype,
                           void* stream);
+/* 1 iff the finish launch of *p (split_k filled in as imd_conv_gemm will see it) can apply GroupNorm(gn_out_groups) (+ SiLU) to its output */
+int imd_conv_gemm_gn_out_supported(const imd_conv_gemm_params* p);
 /* 1 iff imd_attention accepts imd_attn_params.out_dup for this head count / query count / head dim (with k_pad_one = 1) */
 int imd_attention_dup_supported(int H, int N, int D);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
