@@ -45,6 +45,8 @@ class ConvGemmParams(_Sized):
         ("gn_a", C.c_void_p), ("gn_b", C.c_void_p), ("gn_silu", C.c_int), ("pad_br_only", C.c_int),
         ("splitk_counters", C.c_void_p),
         ("gn_stats_out", C.c_void_p), ("gn_stats_groups", C.c_int),
+        ("gn_in_partial", C.c_void_p), ("gn_in_gamma", C.c_void_p), ("gn_in_beta", C.c_void_p),
+        ("gn_in_nparts", C.c_int), ("gn_in_groups", C.c_int), ("gn_in_silu", C.c_int), ("gn_in_eps", C.c_float),
         ("gn_out_gamma", C.c_void_p), ("gn_out_beta", C.c_void_p), ("gn_out_eps", C.c_float), ("gn_out_silu", C.c_int), ("gn_out_groups", C.c_int),
     ]
 
@@ -121,6 +123,7 @@ SYMBOLS = {
     "imd_conv_patch_stats_parts": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_conv_gemm_stats_parts": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int]),
     "imd_conv_gemm_gn_out_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
+    "imd_row_linear_gn_in_supported": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int]),
     "imd_gemm_dma_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),
     "imd_row_linear": (C.c_int, [C.POINTER(ConvGemmParams), C.c_int, C.c_float, C.c_void_p]),
     "imd_row_linear_supported": (C.c_int, [C.POINTER(ConvGemmParams)]),

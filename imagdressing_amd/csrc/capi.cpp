@@ -190,6 +190,7 @@ int imd_conv_patch4_supported(const imd_conv_gemm_params* p) { return query(p, s
 int imd_conv_img_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_conv_img_supported)); }
 int imd_conv_patch_stats_parts(const imd_conv_gemm_params* p) { return sized(p) ? imd_conv_patch_stats_parts_of(*p) : 0; }
 int imd_conv_gemm_stats_parts(const imd_conv_gemm_params* p, int cfg) { return sized(p) ? imd_conv_gemm_stats_parts_of(*p, cfg) : 0; }
+int imd_row_linear_gn_in_supported(const imd_conv_gemm_params* p, int cfg) { return (sized(p) && p->gn_in_partial != nullptr && imd_row_linear_gn_in_supported_of(*p, cfg)) ? 1 : 0; }
 int imd_conv_gemm_gn_out_supported(const imd_conv_gemm_params* p) { return (sized(p) && imd_conv_gemm_gn_out_supported_of(*p, -1)) ? 1 : 0; }
 int imd_gemm_dma_supported(const imd_conv_gemm_params* p) { return query(p, static_cast<bool (*)(const imd_conv_gemm_params&)>(imd_gemm_dma_supported)); }
 
@@ -207,7 +208,10 @@ int imd_row_linear(const imd_conv_gemm_params* p, int ln, float ln_eps, void* st
         IMD_REQUIRE(!p->out_f32, "row_linear: head-split output excludes fp32 output");
     }
     IMD_REQUIRE(!ln || ln_eps > 0.f, "row_linear: LayerNorm needs eps > 0");
-    if (p->K == 320 && p->N == 960 && p->mode == IMD_OUT_HEADS) return imd_launch_row_qkv(*p, ln, ln_eps, (hipStream_t)stream);
+    if (p->K == 320 && p->N == 960 && p->mode == IMD_OUT_HEADS) {
+        IMD_REQUIRE(p->gn_in_partial == nullptr, "row_linear: the fused q / k / v projection has no GroupNorm prologue (gn_in_*)");
+        return imd_launch_row_qkv(*p, ln, ln_eps, (hipStream_t)stream);
+    }
     if (p->K == 640) return imd_launch_row_linear_k640(*p, ln, ln_eps, (hipStream_t)stream);
     if (p->K == 1280) return imd_launch_row_linear_k1280(*p, ln, ln_eps, (hipStream_t)stream);
     return imd_launch_row_linear(*p, ln, ln_eps, (hipStream_t)stream);

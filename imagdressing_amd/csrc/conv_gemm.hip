@@ -589,6 +589,19 @@ int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     return (cfg == 5 || cfg == 29) ? imd_conv_patch_stats_parts_of(p) : 0;
 }
 
+// can tile config `cfg` normalise its input rows as p.gn_in_* asks (the row-resident projections only)?
+bool imd_row_linear_gn_in_supported_of(const ConvGemmParams& p, int cfg) {
+    if (p.gn_in_partial == nullptr) return true;
+    ConvGemmParams q = p;
+    q.split_k = 1;
+    switch (cfg) {
+        case 12: return imd_row_linear_supported(q) && gn_in_ok(q, 320, 128);
+        case 13: return imd_row_linear_k640_supported(q) && gn_in_ok(q, 640, 128);
+        case 14: return imd_row_linear_k1280_supported(q) && gn_in_ok(q, 1280, 64);
+        default: return false;
+    }
+}
+
 // can the finish launch of `p` (tile config `cfg`) normalise its output (gn_out_*)?  The in-kernel K-slice sum (splitk_counters) is simply not used then.
 bool imd_conv_gemm_gn_out_supported_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
@@ -698,6 +711,9 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("conv_gemm: unknown dtype %d", p.dtype);
     if ((p.gn_a != nullptr) != (p.gn_b != nullptr)) return imd_set_error("conv_gemm: gn_a and gn_b must be given together");
     if (p.gn_a != nullptr && cfg != 5) return imd_set_error("conv_gemm: the fused GroupNorm prologue needs tile config 5 (got %d)", cfg);
+    if (p.gn_in_partial != nullptr && !imd_row_linear_gn_in_supported_of(p, cfg))
+        return imd_set_error("conv_gemm: gn_in_* (GroupNorm of the input rows) exists in the row-resident projections only (tile configs 12 / 13 / 14 with H W a multiple of "
+                             "their row block; got cfg=%d K=%d HW=%d): ask imd_row_linear_gn_in_supported() first", cfg, p.K, p.Hout * p.Wout);
     const bool h = p.dtype == IMD_DTYPE_F16;
     switch (cfg) {
         case 0: return h ? launch_cfg<true, 128, 128, 64, 2, 2>(p, s) : launch_cfg<false, 128, 128, 64, 2, 2>(p, s);

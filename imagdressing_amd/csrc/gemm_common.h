@@ -59,6 +59,98 @@ __device__ __forceinline__ void xcd_tile_order(int flags, int m_tiles, int n_til
 // ------------------------------------------------------------------------------------------
 // shared epilogue on 8 consecutive channels [n, n+8) of row m (nv = number of valid channels: 4 or 8)
 // ------------------------------------------------------------------------------------------
+// GroupNorm of the INPUT rows inside a row-resident projection (imd_conv_gemm_params.gn_in_*, round 6): per-channel coefficients of image `b`
+// into LDS scratch -- a[k] = gamma[k] rstd[g(k)], sh[k] = beta[k] - mean[g(k)] a[k] -- from the statistic partials of x, folded in EXACTLY the order
+// gn_apply_kernel (norm.hip, 320 threads: group = tid % G, every (320 / G)-th partial each, then a serial sum over the 320 / G lanes) folds them, so
+// that the fused launch is bit-identical to imd_groupnorm + the projection.  All threads of the workgroup call it (three barriers inside).
+// scratch: 2 * 320 + 128 + 2 * K floats.  Returns the coefficient arrays through a / sh.
+template <int K>
+__device__ __forceinline__ void gn_in_coeffs(const ConvGemmParams& p, int b, float* scratch, const float*& a, const float*& sh) {
+    constexpr int T = 320;
+    float* red_s = scratch;
+    float* red_q = scratch + T;
+    float* s_mean = scratch + 2 * T;
+    float* s_rstd = s_mean + 64;
+    float* s_a = s_rstd + 64;
+    float* s_sh = s_a + K;
+    const int tid = threadIdx.x;
+    const int Gn = p.gn_in_groups, cpg = K / Gn, nchunks = p.gn_in_nparts;
+    if (tid < T) {
+        const int parts = T / Gn;
+        const int g = tid % Gn, part = tid / Gn;
+        float S = 0.f, Q = 0.f;
+        // a thread's partials are requested TOGETHER (up to MAXP of them; the usual 96 .. 128 per image are 10 .. 13 per thread) and summed in the same
+        // ascending order afterwards: as a run-time loop the fold is a chain of ~10 dependent trips to the L2 that every workgroup of the launch waits out
+        constexpr int MAXP = 13;
+        if (nchunks <= MAXP * parts) {
+            float2 pv[MAXP];
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int c = part + i * parts;
+                pv[i] = (part < parts && c < nchunks) ? *reinterpret_cast<const float2*>(p.gn_in_partial + (((size_t)b * nchunks + c) * Gn + g) * 2) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int c = part + i * parts;
+                if (part < parts && c < nchunks) { S += pv[i].x; Q += pv[i].y; }
+            }
+        } else if (part < parts) {
+            for (int c = part; c < nchunks; c += parts) {
+                const float2 v = *reinterpret_cast<const float2*>(p.gn_in_partial + (((size_t)b * nchunks + c) * Gn + g) * 2);
+                S += v.x; Q += v.y;
+            }
+        }
+        red_s[tid] = S; red_q[tid] = Q;
+    }
+    __syncthreads();
+    if (tid < Gn) {
+        const int parts = T / Gn;
+        float St = 0.f, Qt = 0.f;
+        for (int k = 0; k < parts; ++k) { St += red_s[k * Gn + tid]; Qt += red_q[k * Gn + tid]; }
+        const float n = (float)(p.Hout * p.Wout) * (float)cpg;
+        const float mean = St / n;
+        const float var = fmaxf(Qt / n - mean * mean, 0.f);
+        s_mean[tid] = mean;
+        s_rstd[tid] = rsqrtf(var + p.gn_in_eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < K; c += (int)blockDim.x) {
+        const int g = c / cpg;
+        const float ga = p.gn_in_gamma[c] * s_rstd[g];
+        s_a[c] = ga;
+        s_sh[c] = p.gn_in_beta[c] - s_mean[g] * ga;
+    }
+    __syncthreads();
+    a = s_a; sh = s_sh;
+}
+
+// one 8-channel fragment (channels k0 .. k0 + 7) of a row through y = x a + sh (+ SiLU), rounded back to the element type -- gn_apply_kernel's arithmetic
+template <bool F16>
+__device__ __forceinline__ uint4 gn_in_apply8(const uint4& raw, const float* a, const float* sh, int k0, bool silu) {
+    const float4 a0 = *reinterpret_cast<const float4*>(a + k0), a1 = *reinterpret_cast<const float4*>(a + k0 + 4);
+    const float4 s0 = *reinterpret_cast<const float4*>(sh + k0), s1 = *reinterpret_cast<const float4*>(sh + k0 + 4);
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float f[8];
+    unpack8<F16>(raw, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float y = f[e] * av[e] + sv[e];
+        if (silu) y = silu_f(y);
+        f[e] = y;
+    }
+    return pack8<F16>(f);
+}
+
+// can a row-resident kernel with `rows` rows per workgroup and K input channels take p's gn_in_* request?
+inline bool gn_in_ok(const ConvGemmParams& p, int K, int rows) {
+    if (p.gn_in_partial == nullptr) return true;
+    const int HW = p.Hout * p.Wout;
+    // (row-major output, no residual: the GN instantiations fix the epilogue's run-time forks at compile time -- Transformer2DModel.proj_in has neither)
+    return p.mode == OUT_ROWMAJOR && p.res == nullptr && p.gn_in_gamma != nullptr && p.gn_in_beta != nullptr && p.gn_in_groups > 0 && p.gn_in_groups <= 64 && (K % p.gn_in_groups) == 0 &&
+           p.gn_in_nparts > 0 && p.gn_in_nparts <= 4096 && HW > 0 && (HW % rows) == 0 && (p.M % HW) == 0 && p.K == K;
+}
+
+// ------------------------------------------------------------------------------------------
 // per-column addends of 8 channels [n, n+8): bias[n..] (+ the per-batch vector of batch entry `bi` when given)
 __device__ __forceinline__ void load_col_addends(const ConvGemmParams& p, int bi, int n, int nv, float4& a0, float4& a1) {
     a0 = make_float4(0, 0, 0, 0); a1 = a0;

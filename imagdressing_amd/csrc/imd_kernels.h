@@ -45,6 +45,7 @@ int imd_launch_conv_img(const ConvGemmParams& p, hipStream_t s);
 int imd_conv_patch_stats_parts_of(const ConvGemmParams& p);
 int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p, int cfg);
 bool imd_conv_gemm_gn_out_supported_of(const ConvGemmParams& p, int cfg);
+bool imd_row_linear_gn_in_supported_of(const ConvGemmParams& p, int cfg);
 int imd_launch_conv_patch(const ConvGemmParams& p, hipStream_t s);
 bool imd_row_linear_supported(const ConvGemmParams& p);                                    // row_linear.hip
 int imd_launch_row_linear(const ConvGemmParams& p, int ln, float ln_eps, hipStream_t s);

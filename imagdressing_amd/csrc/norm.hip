@@ -127,7 +127,22 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormPar
         const int parts = GN_THREADS / p.G;
         const int g = tid % p.G, part = tid / p.G;
         float S = 0.f, Q = 0.f;
-        if (part < parts) {
+        // (round 6) a thread's partials are requested TOGETHER and summed in the same ascending order afterwards (gemm_common.h::gn_in_coeffs does the
+        // same): as a run-time loop the fold is a chain of ~10 dependent trips to the L2 in front of every block's streaming phase
+        constexpr int MAXP = 13;
+        if (nchunks <= MAXP * parts) {
+            float2 pv[MAXP];
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int c = part + i * parts;
+                pv[i] = (part < parts && c < nchunks) ? *reinterpret_cast<const float2*>(p.partial + (((size_t)b * nchunks + c) * p.G + g) * 2) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) {
+                const int c = part + i * parts;
+                if (part < parts && c < nchunks) { S += pv[i].x; Q += pv[i].y; }
+            }
+        } else if (part < parts) {
             for (int c = part; c < nchunks; c += parts) {
                 const float2 v = *reinterpret_cast<const float2*>(p.partial + (((size_t)b * nchunks + c) * p.G + g) * 2);
                 S += v.x; Q += v.y;

@@ -41,8 +41,10 @@ constexpr int RL_LDS = RL_RING * RL_CHUNK;       // 122880 >= 64 * RL_CLD * 4 = 
 constexpr int RL_LDS_TOTAL = RL_LDS + 320 * 4;   // + the bias vector of the direct epilogue
 static_assert(RL_PIECES == 5, "dma_wait_keep5 assumes five pieces per chunk");
 
-template <bool F16, int NC, bool LN, bool DIRECT>
+// GN (round 6): GroupNorm (+ SiLU) of the rows from the statistic partials of x (imd_conv_gemm_params.gn_in_*) -- Transformer2DModel.norm -> proj_in in one launch
+template <bool F16, int NC, bool LN, bool DIRECT, bool GN = false>
 __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams p, const float ln_eps) {
+    static_assert(!(LN && GN), "one prologue at a time");
     using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -68,8 +70,11 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     // everything else should hide under them).  The residual of chunk c is requested while chunk c is multiplied and
     // consumed one chunk later, so its 21 MB ride under the output stream as well; the bias sits in LDS behind the ring.
     uint4 rraw[2][2];                                            // residual of a chunk: per register-group pair t, (group 2 t | group 2 t + 1) or, wide, 8 consecutive channels
-    const bool wide = (p.flags & 1024) != 0;                     // 16-byte stores / residual loads (see emit)
-    const bool has_res = DIRECT && !LN && p.res != nullptr;      // (LayerNorm + residual: staged epilogue)
+    // (GN: the launcher sends row-major outputs without residual only -- Transformer2DModel.proj_in -- so the epilogue's run-time forks are compile-time
+    // there: with them AND the prologue in one body hipcc spilled 190 registers)
+    const bool wide = GN || (p.flags & 1024) != 0;               // 16-byte stores / residual loads (see emit)
+    const bool has_res = DIRECT && !LN && !GN && p.res != nullptr;      // (LayerNorm + residual: staged epilogue)
+    const bool heads = !GN && p.mode == OUT_HEADS;
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, 0x80000000u, 0x00020000);
     const uint32_t roff = (uint32_t)m * (uint32_t)(p.res_ld * 2) + (uint32_t)((wave >> 2) * 64);
     auto load_res = [&](int c) {        // residual of chunk c: lane = token; 8 consecutive channels per 16-byte load (wide; put into the accumulator layout
@@ -147,6 +152,19 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
         }
     }
 
+    if constexpr (GN) {      // rows normalised in place with the per-channel coefficients of this workgroup's image (its 128 rows lie in ONE image)
+        // scratch = ring slot 2: no DMA piece lands there before stage(2), which is issued behind the first barrier of the chunk loop
+        const float *ga, *gs;
+        gn_in_coeffs<RL_K>(p, m0 / (p.Hout * p.Wout), reinterpret_cast<float*>(smem + 2 * RL_CHUNK), ga, gs);
+        const bool silu = p.gn_in_silu != 0;
+#pragma unroll
+        for (int s = 0; s < RL_STEPS; ++s) {       // (one fragment at a time: left alone hipcc hoists all 80 coefficient reads and spills 190 registers)
+            xf[s] = gn_in_apply8<F16>(xf[s], ga, gs, 16 * s + 8 * hi, silu);
+            asm volatile("" ::: "memory");        // (keeps the coefficient reads of the next fragment behind this one)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
     f32x16 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -156,10 +174,10 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     // direct epilogue of chunk c: channels c*64 + chh*32 + 8j + 4hi .. +3 of token m
     const int HWo = p.Hout * p.Wout;
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
-        p.mode == OUT_HEADS ? (void*)p.hd[0].ptr : p.out, 0, 0x80000000u, 0x00020000);
+        heads ? (void*)p.hd[0].ptr : p.out, 0, 0x80000000u, 0x00020000);
     uint32_t obase = OOB;            // byte offset of (token m, channel 0) in the row-major case / of (bi, head 0, tok, 0) for head-split Q
     if (DIRECT && m < p.M) {
-        if (p.mode == OUT_HEADS) { const int bi = m / HWo, tok = m - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
+        if (heads) { const int bi = m / HWo, tok = m - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
         else obase = (uint32_t)m * (uint32_t)(p.out_ld * 2);
     }
     // WIDE stores (round 5): the accumulator layout gives a lane 4 channels of a row, so an 8-byte store instruction puts 16 contiguous bytes
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
                 rres[2 * t] = make_uint2(r.x, r.y); rres[2 * t + 1] = make_uint2(r.z, r.w);
             }
         }
-        const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
+        const float osc = heads ? p.out_scale * p.hd[0].scale : p.out_scale;
         typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
         typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u_t;
         v2u pk[4];
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
             pk[j] = v2u{E::pack2(v0, v1), E::pack2(v2, v3)};
         }
         auto offset_of = [&](int n) -> uint32_t {
-            if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; return (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
+            if (heads) { const int h = n / p.hD, dd = n - h * p.hD; return (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
             return (uint32_t)(n * 2);
         };
         if (wide) {
@@ -269,9 +287,9 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     }
 }
 
-template <bool F16, int NC, bool LN, bool DIRECT>
+template <bool F16, int NC, bool LN, bool DIRECT, bool GN = false>
 int launch_rl_d(const ConvGemmParams& p, float eps, hipStream_t s) {
-    auto kern = row_linear_kernel<F16, NC, LN, DIRECT>;
+    auto kern = row_linear_kernel<F16, NC, LN, DIRECT, GN>;
     if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), RL_LDS_TOTAL, "row_linear")) return rc_attr;
     hipLaunchKernelGGL(kern, dim3((unsigned)((p.M + RL_BM - 1) / RL_BM)), dim3(512), RL_LDS_TOTAL, s, p, eps);
     return imd_check_launch("row_linear");
@@ -283,6 +301,12 @@ int launch_rl(const ConvGemmParams& p, float eps, hipStream_t s) {
                         (p.mode == OUT_ROWMAJOR || (p.hd[0].kind == 0 && p.hd[0].ptr != nullptr && p.N == p.hC));
     const size_t ob = p.mode == OUT_HEADS ? (size_t)(p.M / (p.Hout * p.Wout)) * p.hH * p.hd[0].L * p.hd[0].DP * 2 : ((size_t)(p.M - 1) * p.out_ld + p.N) * 2;
     const size_t rb = p.res ? ((size_t)(p.M - 1) * p.res_ld + p.N) * 2 : 0;
+    if (p.gn_in_partial != nullptr) {        // (never together with LN: refused by the launcher)
+        if constexpr (!LN) {
+            if (direct && ob < 0x80000000ull && rb < 0x80000000ull) return launch_rl_d<F16, NC, false, true, true>(p, eps, s);
+            return launch_rl_d<F16, NC, false, false, true>(p, eps, s);
+        }
+    }
     if (direct && !(LN && p.res) && ob < 0x80000000ull && rb < 0x80000000ull) return launch_rl_d<F16, NC, LN, true>(p, eps, s);
     return launch_rl_d<F16, NC, LN, false>(p, eps, s);
 }
@@ -310,6 +334,8 @@ int imd_launch_row_linear(const ConvGemmParams& p_in, int ln, float ln_eps, hipS
     ConvGemmParams p = p_in;
     if (!imd_row_linear_supported(p))
         return imd_set_error("row_linear: needs a plain linear layer with K = 320 and N = 64..320 in steps of 64 (got N=%d K=%d taps=%d split=%d)", p.N, p.K, p.taps, p.split_k);
+    if (p.gn_in_partial != nullptr && (ln || !gn_in_ok(p, RL_K, RL_BM)))
+        return imd_set_error("row_linear: gn_in_* needs K = 320, K %% groups == 0, groups <= 64, H W %% 128 == 0 and no LayerNorm prologue (ask imd_row_linear_gn_in_supported())");
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("row_linear: unknown dtype %d", p.dtype);
     const size_t xb = ((size_t)(p.M - 1) * p.x_pix_stride + p.K) * 2, wb = (size_t)p.N * p.K * 2;
     if (xb >= 0xffffffffull) return imd_set_error("row_linear: operand larger than 4 GiB");

@@ -46,8 +46,10 @@ template <> struct Mfma16<true> {
 // v_mfma_f32_16x16x32: A lane l = row l & 15, k slots 8 (l >> 4) .. + 7;  B lane l = column l & 15, same k slots;
 // D lane l = column l & 15, rows 4 (l >> 4) + r in register r.  Issued with A = weight rows (channels), B = token rows.
 
-template <bool F16, bool LN>
+// GN (round 6): GroupNorm (+ SiLU) of the rows from the statistic partials of x (gn_in_*; see row_linear.hip)
+template <bool F16, bool LN, bool GN = false>
 __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemmParams p, const float ln_eps) {
+    static_assert(!(LN && GN), "one prologue at a time");
     using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
     // step is shorter than a trip to HBM here, so fetching it one chunk ahead (as the wider kernels do) stalls every step
     const bool owner = kq < 2;
     const int mo = m0 + (kq & 1) * 16 + col;
-    const bool has_res = owner && p.res != nullptr;
+    const bool has_res = !GN && owner && p.res != nullptr;      // (GN: row-major output without residual only, see row_linear.hip)
     uint2 rres[R12_NC];
     if (has_res) {
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, 0x80000000u, 0x00020000);
@@ -109,6 +111,20 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
 #pragma unroll
         for (int s = 0; s < R12_STEPS; ++s) asm volatile("" : "+v"(xf[th][s].x), "+v"(xf[th][s].y), "+v"(xf[th][s].z), "+v"(xf[th][s].w));
     if (tid < R12_NG) reinterpret_cast<float*>(smem + R12_OFF_BIAS)[tid] = bias_v;
+
+    if constexpr (GN) {      // (scratch = ring slot 2: nothing lands there before stage(2), issued behind the chunk loop's first barrier; the 64 rows lie in ONE image)
+        const float *ga, *gs;
+        gn_in_coeffs<R12_K>(p, (mblk * 64) / (p.Hout * p.Wout), reinterpret_cast<float*>(smem + 2 * R12_CHUNK), ga, gs);
+        const bool silu = p.gn_in_silu != 0;
+#pragma unroll
+        for (int th = 0; th < 2; ++th)
+#pragma unroll
+            for (int s = 0; s < R12_STEPS; ++s) {  // (one fragment at a time: see row_linear.hip)
+                xf[th][s] = gn_in_apply8<F16>(xf[th][s], ga, gs, kq * R12_KQ + 32 * s + 8 * g, silu);
+                asm volatile("" ::: "memory");        // (keeps the coefficient reads of the next fragment behind this one)
+            __builtin_amdgcn_sched_barrier(0);
+            }
+    }
 
     if constexpr (LN) {      // LayerNorm without affine over all 1280 channels: a token's row is spread over 4 lanes (g) x 4 waves (kq)
         float* lnx = reinterpret_cast<float*>(smem + R12_OFF_LN);           // [8 waves][2 th][64 lanes]
@@ -185,15 +201,16 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
 
     // ---- output side: waves kq = 0 / 1 own token half 0 / 1: channels n0 + 16 c + 4 g .. + 3 of token m0 + 16 kq + col ----
     const int HWo = p.Hout * p.Wout;
-    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.mode == OUT_HEADS ? (void*)p.hd[0].ptr : p.out, 0, 0x80000000u, 0x00020000);
+    const bool heads = !GN && p.mode == OUT_HEADS;
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(heads ? (void*)p.hd[0].ptr : p.out, 0, 0x80000000u, 0x00020000);
     uint32_t obase = OOB;
     if (owner && mo < p.M) {
-        if (p.mode == OUT_HEADS) { const int bi = mo / HWo, tok = mo - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
+        if (heads) { const int bi = mo / HWo, tok = mo - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
         else obase = (uint32_t)mo * (uint32_t)(p.out_ld * 2);
     }
     float4* red = reinterpret_cast<float4*>(smem + R12_OFF_RED);          // [2 buffers][2 tb][4 kq][2 th][64 lanes]
     const float* bias_s = reinterpret_cast<const float*>(smem + R12_OFF_BIAS);
-    const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
+    const float osc = heads ? p.out_scale * p.hd[0].scale : p.out_scale;
     f32x4 own;                         // the owner's own partial sums of the previous chunk
     own[0] = own[1] = own[2] = own[3] = 0.f;
     auto emit = [&](int c) {           // owners only: chunk c = own + three foreign partials, bias, scale, residual, one 8-byte store
@@ -213,7 +230,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
         }
         const int n = n0 + nl;
         uint32_t off;
-        if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; off = (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
+        if (heads) { const int h = n / p.hD, dd = n - h * p.hD; off = (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
         else off = (uint32_t)(n * 2);
         typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
         const v2u pk = {E::pack2(v0, v1), E::pack2(v2, v3)};
@@ -249,9 +266,9 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
     }
 }
 
-template <bool F16, bool LN>
+template <bool F16, bool LN, bool GN = false>
 int launch_r12(const ConvGemmParams& p, float eps, hipStream_t s) {
-    auto kern = row_linear_k1280_kernel<F16, LN>;
+    auto kern = row_linear_k1280_kernel<F16, LN, GN>;
     if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), R12_LDS, "row_linear_k1280")) return rc_attr;
     const unsigned grid = (unsigned)((((p.M + 63) / 64 + 7) / 8) * 8 * (p.N / R12_NG));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), R12_LDS, s, p, eps);
@@ -283,6 +300,11 @@ int imd_launch_row_linear_k1280(const ConvGemmParams& p_in, int ln, float ln_eps
     p.split_k = 1;
     p.flags = 0;
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if (p.gn_in_partial != nullptr) {
+        if (ln || !gn_in_ok(p, R12_K, 64))
+            return imd_set_error("row_linear_k1280: gn_in_* needs K = 1280, K %% groups == 0, groups <= 64, H W %% 64 == 0 and no LayerNorm prologue (ask imd_row_linear_gn_in_supported())");
+        return h ? launch_r12<true, false, true>(p, ln_eps, s) : launch_r12<false, false, true>(p, ln_eps, s);
+    }
     if (ln) return h ? launch_r12<true, true>(p, ln_eps, s) : launch_r12<false, true>(p, ln_eps, s);
     return h ? launch_r12<true, false>(p, ln_eps, s) : launch_r12<false, false>(p, ln_eps, s);
 }

@@ -33,8 +33,10 @@ constexpr int R6_OFF_BIAS = R6_OFF_RED + 2 * 8 * 2048;     // 155648
 constexpr int R6_OFF_LN = R6_OFF_BIAS + R6_NG * 4;         // 156288: LayerNorm partials, 8 waves x 64 lanes x 8 B
 constexpr int R6_LDS = R6_OFF_LN + 8 * 64 * 8;             // 160384 <= 163840
 
-template <bool F16, bool LN>
+// GN (round 6): GroupNorm (+ SiLU) of the rows from the statistic partials of x (gn_in_*; see row_linear.hip)
+template <bool F16, bool LN, bool GN = false>
 __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmParams p, const float ln_eps) {
+    static_assert(!(LN && GN), "one prologue at a time");
     using E = El<F16>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -123,19 +125,32 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
         }
     }
 
+    if constexpr (GN) {      // (scratch = ring slot 2: nothing lands there before stage(2), issued behind the chunk loop's first barrier)
+        const float *ga, *gs;
+        gn_in_coeffs<R6_K>(p, m0 / (p.Hout * p.Wout), reinterpret_cast<float*>(smem + 2 * R6_CHUNK), ga, gs);
+        const bool silu = p.gn_in_silu != 0;
+#pragma unroll
+        for (int s = 0; s < R6_STEPS; ++s) {       // (one fragment at a time: see row_linear.hip)
+            xf[s] = gn_in_apply8<F16>(xf[s], ga, gs, kh * R6_KH + 16 * s + 8 * hi, silu);
+            asm volatile("" ::: "memory");        // (keeps the coefficient reads of the next fragment behind this one)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
     // ---- output side: this wave stores quads {2 kh, 2 kh + 1} of every chunk: channels n0 + 32 c + 8 q + 4 hi .. + 3 ----
     const int HWo = p.Hout * p.Wout;
-    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(p.mode == OUT_HEADS ? (void*)p.hd[0].ptr : p.out, 0, 0x80000000u, 0x00020000);
+    const bool heads = !GN && p.mode == OUT_HEADS;        // (GN: row-major output without residual only, see row_linear.hip)
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(heads ? (void*)p.hd[0].ptr : p.out, 0, 0x80000000u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, 0x80000000u, 0x00020000);
     uint32_t obase = OOB;
     if (m < p.M) {
-        if (p.mode == OUT_HEADS) { const int bi = m / HWo, tok = m - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
+        if (heads) { const int bi = m / HWo, tok = m - bi * HWo; obase = (uint32_t)(((size_t)bi * p.hH * p.hd[0].L + tok) * p.hd[0].DP * 2); }
         else obase = (uint32_t)m * (uint32_t)(p.out_ld * 2);
     }
-    const bool has_res = p.res != nullptr;
+    const bool has_res = !GN && p.res != nullptr;
     const uint32_t roff = (uint32_t)m * (uint32_t)(p.res_ld * 2);
     uint4 rraw[2];                     // residual of a chunk: (quad 2 kh | quad 2 kh + 1) in accumulator layout or, wide, 8 consecutive channels
-    const bool wide = (p.flags & 1024) != 0;      // 16-byte stores / residual loads of 8 consecutive channels (row_linear.hip: "WIDE stores"); knob 2 bit 10 = the 8-byte form
+    const bool wide = GN || (p.flags & 1024) != 0;      // 16-byte stores / residual loads of 8 consecutive channels (row_linear.hip: "WIDE stores"); knob 2 bit 10 = the 8-byte form
     auto load_res = [&](int c) {
         if (wide) rraw[c & 1] = buf_load16(rs_r, m < p.M ? roff + (uint32_t)((n0 + 32 * c + 16 * kh + 8 * hi) * 2) : OOB);
         else {
@@ -146,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
     };
     float4* red = reinterpret_cast<float4*>(smem + R6_OFF_RED);          // [2][8 waves][2 quads][64 lanes]
     const float* bias_s = reinterpret_cast<const float*>(smem + R6_OFF_BIAS);
-    const float osc = p.mode == OUT_HEADS ? p.out_scale * p.hd[0].scale : p.out_scale;
+    const float osc = heads ? p.out_scale * p.hd[0].scale : p.out_scale;
     float own[8];                      // this wave's two quads of the previous chunk (its own partial sums)
     auto emit = [&](int c) {           // chunk c: own partial + the partner's, bias, scale, residual, one 16-byte (or two 8-byte) stores
         typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
@@ -176,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
             pk[j] = v2u{E::pack2(v0, v1), E::pack2(v2, v3)};
         }
         auto offset_of = [&](int n) -> uint32_t {
-            if (p.mode == OUT_HEADS) { const int h = n / p.hD, dd = n - h * p.hD; return (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
+            if (heads) { const int h = n / p.hD, dd = n - h * p.hD; return (uint32_t)((h * p.hd[0].L * p.hd[0].DP + dd) * 2); }
             return (uint32_t)(n * 2);
         };
         if (wide) {                    // quads 2 kh (channels 16 kh + 4 hi ..) and 2 kh + 1 (16 kh + 8 + 4 hi ..) -> channels 16 kh + 8 hi + 0..7 of the chunk
@@ -223,9 +238,9 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
     }
 }
 
-template <bool F16, bool LN>
+template <bool F16, bool LN, bool GN = false>
 int launch_r6(const ConvGemmParams& p, float eps, hipStream_t s) {
-    auto kern = row_linear_k640_kernel<F16, LN>;
+    auto kern = row_linear_k640_kernel<F16, LN, GN>;
     if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), R6_LDS, "row_linear_k640")) return rc_attr;
     const unsigned grid = (unsigned)((((p.M + 127) / 128 + 7) / 8) * 8 * (p.N / R6_NG));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), R6_LDS, s, p, eps);
@@ -257,6 +272,11 @@ int imd_launch_row_linear_k640(const ConvGemmParams& p_in, int ln, float ln_eps,
     p.split_k = 1;
     p.flags = (g_gemm_flags & 1024) ? 0 : 1024;        // bit 10: wide (16-byte) stores of the direct epilogue
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if (p.gn_in_partial != nullptr) {
+        if (ln || !gn_in_ok(p, R6_K, 128))
+            return imd_set_error("row_linear_k640: gn_in_* needs K = 640, K %% groups == 0, groups <= 64, H W %% 128 == 0 and no LayerNorm prologue (ask imd_row_linear_gn_in_supported())");
+        return h ? launch_r6<true, false, true>(p, ln_eps, s) : launch_r6<false, false, true>(p, ln_eps, s);
+    }
     if (ln) return h ? launch_r6<true, true>(p, ln_eps, s) : launch_r6<false, true>(p, ln_eps, s);
     return h ? launch_r6<true, false>(p, ln_eps, s) : launch_r6<false, false>(p, ln_eps, s);
 }

@@ -162,6 +162,8 @@ FUSED_GN_CONV = _os.environ.get("IMD_FUSED_GN_CONV", "0") == "1"
 # OPT-IN: correct and tested, measured neutral at the bench batch (592.0 vs 592.6 ms) and 1.1 % SLOWER at batch 1 (350.8 -> 354.9 ms), same box,
 # interleaved twice (profiles/r6h_*): a workgroup per (image, group) reads 160-byte column strips of the fp32 slabs where the plain finish reads whole rows
 FUSED_GN_FINISH = _os.environ.get("IMD_FUSED_GN_FINISH", "0") == "1"
+# (round 6) Transformer2DModel.norm inside proj_in's row-resident launch (gn_in_*): the normalised tensor never exists in memory (A/B switch)
+FUSED_GN_PROJ = _os.environ.get("IMD_FUSED_GN_PROJ", "1") != "0"
 CFG_PAIR_ATTN = _os.environ.get("IMD_CFG_PAIR_ATTN", "1") != "0"     # ... and the first hybrid block up to its self-attention phase (unet.Transformer2D.call_pair_half; A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
@@ -247,7 +249,7 @@ def conv_gemm(
     act: int = ACT_NONE, out_f32: bool = False,
     heads: Optional[dict] = None, cfg: int = -1, split_k: int = 0,
     gn: Optional[tuple] = None, pad_br_only: bool = False, ln_eps: Optional[float] = None, gn_stats_groups: int = 0,
-    gn_out: Optional[tuple] = None,
+    gn_out: Optional[tuple] = None, gn_in: Optional[tuple] = None,
 ) -> Optional[torch.Tensor]:
     """out[M, N] = epilogue(A(M, K) @ w[N, K]^T); see include/imagdressing_hip.h::imd_conv_gemm.
 
@@ -258,6 +260,9 @@ def conv_gemm(
     ``ln_eps``: LayerNorm WITHOUT affine over the K channels of every row of ``x`` is applied on the fly (row-resident kernel,
     K = 320 and N <= 320 only; fold gamma / beta into ``w`` / ``bias`` with :func:`fold_layernorm_affine`).
     ``gn_stats_groups`` = G: when the launch lands on the halo-patch kernel without K slices, or is K-sliced with a separate finish launch,
+    ``gn_in`` = (gamma, beta, eps, silu, groups): GroupNorm (+ SiLU) of the INPUT ``x`` [B, HW, K] of a plain linear layer.  Where the layer runs on a
+    row-resident projection kernel (tile configs 12 / 13 / 14) and ``x`` carries its producer's statistics (``_imd_gn_stats``) the normalisation happens inside
+    that launch (``imd_conv_gemm_params.gn_in_*``: bit-identical, no normalised tensor in memory); everywhere else :func:`group_norm` runs first.
     ``gn_out`` = (gamma, beta, eps, silu, groups): where the problem is K-sliced with a separate finish launch and that launch can own whole
     (image, group) slabs (``imd_conv_gemm_gn_out_supported``: the 16x16 / 8x8 levels), the finish launch applies GroupNorm (+ SiLU) to its output
     itself; the returned tensor then carries ``_imd_gn_applied = True`` and holds the NORMALISED values.  Ignored (raw output) everywhere else.
@@ -371,6 +376,25 @@ def conv_gemm(
     if dkey is not None and len(_CFG_DECISIONS) < 4096:
         _CFG_DECISIONS[dkey] = (cfg, split_k)
     p.split_k = split_k
+    if gn_in is not None:
+        # Transformer2DModel.norm -> proj_in: inside the projection launch where that launch is a row-resident kernel and x came with its statistics
+        gi_gamma, gi_beta, gi_eps, gi_silu, gi_groups = gn_in
+        st = getattr(x, "_imd_gn_stats", None)
+        fused = False
+        if FUSED_GN_PROJ and cfg in (12, 13, 14) and st is not None and st[2] == gi_groups and FUSED_GN_STATS and st[0].shape[0] * Hout * Wout == M:
+            p.gn_in_partial, p.gn_in_nparts, p.gn_in_groups = st[0].data_ptr(), st[1], int(gi_groups)
+            p.gn_in_gamma, p.gn_in_beta = _dev(gi_gamma, torch.float32, "gn_in gamma"), _dev(gi_beta, torch.float32, "gn_in beta")
+            p.gn_in_eps, p.gn_in_silu = float(gi_eps), int(bool(gi_silu))
+            fused = bool(lib.imd_row_linear_gn_in_supported(C.byref(p), cfg))
+            if not fused:
+                p.gn_in_partial = None
+                p.gn_in_nparts = p.gn_in_groups = 0
+        if not fused:
+            xv = x.view(M // (Hout * Wout), Hout * Wout, Cin)
+            if st is not None:
+                xv._imd_gn_stats = st
+            xn = group_norm(xv, gi_gamma, gi_beta, groups=gi_groups, eps=gi_eps, silu=gi_silu)
+            p.x = _dev(xn, dt, "x")
     if split_k > 1:
         p.splitk_ws = splitk_workspace(split_k * M * N, x.device).data_ptr()
         if SPLITK_IN_KERNEL:
@@ -504,7 +528,7 @@ def ff_geglu_fused(x2d: torch.Tensor, packed: dict, ln_eps: float = 1e-5, out: O
 
 def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1, ups=False, rowvec=None,
                 rowvec_stride=0, rowvec_off=0, res=None, out_scale=1.0, act=ACT_NONE, out_f32=False, cfg=-1, split_k=0, gn=None,
-                pad_br_only=False, gn_stats_groups=0, gn_out=None) -> torch.Tensor:
+                pad_br_only=False, gn_stats_groups=0, gn_out=None, gn_in=None) -> torch.Tensor:
     """x [B, H, W, Cin] bf16 -> [B, Ho, Wo, Cout].  ``pad_br_only``: F.pad(x, (0, 1, 0, 1)) + conv(padding=0) (VAE encoder)."""
     B, H, W, Cin = x.shape
     Cout = w.shape[0]
@@ -513,7 +537,7 @@ def conv2d_nhwc(x: torch.Tensor, w: torch.Tensor, bias=None, *, taps=9, stride=1
     M = B * Ho * Wo
     out = conv_gemm(x, w, M=M, N=Cout, Cin=Cin, taps=taps, Hin=H, Win=W, Hout=Ho, Wout=Wo, stride=stride, ups=ups,
                     bias=bias, rowvec=rowvec, rowvec_stride=rowvec_stride, rowvec_off=rowvec_off, res=res, out_scale=out_scale, act=act,
-                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn, pad_br_only=pad_br_only, gn_stats_groups=gn_stats_groups, gn_out=gn_out)
+                    out_f32=out_f32, cfg=cfg, split_k=split_k, gn=gn, pad_br_only=pad_br_only, gn_stats_groups=gn_stats_groups, gn_out=gn_out, gn_in=gn_in)
     r = out.view(B, Ho, Wo, -1)
     if getattr(out, "_imd_gn_applied", False):
         r._imd_gn_applied = True

@@ -312,8 +312,8 @@ class Transformer2D:
 
     def __call__(self, x, ehs, cak):
         B, H, W, Cc = x.shape
-        h = ops.group_norm(x, self.norm.weight, self.norm.bias, groups=self.groups, eps=1e-6, silu=False)
-        h = self.proj_in(h).view(B, H * W, Cc)
+        # norm -> proj_in: one launch where proj_in runs on a row-resident kernel and x came with its producer's statistics (ops.conv_gemm gn_in)
+        h = self.proj_in(x, gn_in=(self.norm.weight, self.norm.bias, 1e-6, False, self.groups)).view(B, H * W, Cc)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, cak)
         return self.proj_out(h.view(B, H, W, Cc), res=x)
@@ -341,8 +341,7 @@ class Transformer2D:
         Bh, H, W, Cc = x_half.shape
         blk = self.transformer_blocks[0]
         x_full = ops.repeat_batch(x_half)                                  # the transformer's own residual (and the caller's skip tensor)
-        h = ops.group_norm(x_half, self.norm.weight, self.norm.bias, groups=self.groups, eps=1e-6, silu=False)
-        h = self.proj_in(h).view(Bh, H * W, Cc)
+        h = self.proj_in(x_half, gn_in=(self.norm.weight, self.norm.bias, 1e-6, False, self.groups)).view(Bh, H * W, Cc)
         h_full = ops.repeat_batch(h)                                       # attn1's block residual, one copy per half
         h = blk.attn1(h, encoder_hidden_states=None, residual=h_full, layernorm=(blk.norm1, 1e-5), imd_pair_half=True, **cak)
         h = blk.after_attn1(h, ehs, cak)

@@ -111,6 +111,18 @@ typedef struct imd_conv_gemm_params {
      * the value ROUNDED to the element type (what imd_groupnorm would read back), fp32, fixed summation order.  Needs split_k > 1 without
      * splitk_counters, a row-major 16-bit output without activation / GEGLU, N % groups == 0 with 4 | N / groups, and
      * Hout * Wout * (N / groups) <= 12288 (the 16x16 and 8x8 levels); gn_stats_out must be NULL (there is nothing left to normalise). */
+    /* GroupNorm (+ SiLU) of the INPUT rows inside the row-resident projections (ABI v9; imd_row_linear_gn_in_supported(p, cfg); tile configs
+     * 12 / 13 / 14): Transformer2DModel.norm -> proj_in as ONE launch -- the normalised tensor never exists in memory.  gn_in_partial holds the
+     * (sum, sum of squares) partials of x exactly as imd_groupnorm takes them (`partial` + `nparts`: [B][gn_in_nparts][gn_in_groups][2], written by
+     * the producer of x through gn_stats_out or by a statistics pass); every workgroup folds its image's partials in imd_groupnorm's order and
+     * applies  y = x * (gamma rstd) + (beta - mean gamma rstd)  (+ SiLU) to its rows in registers, rounded to the element type -- bit-identical
+     * to imd_groupnorm followed by the same projection.  Needs K = Cin = 320 / 640 / 1280, K % gn_in_groups == 0, gn_in_groups <= 64 and
+     * Hout * Wout a multiple of the kernel's row block (128 / 128 / 64). */
+    const float* gn_in_partial; /* NULL: off */
+    const float* gn_in_gamma;   /* [K] */
+    const float* gn_in_beta;    /* [K] */
+    int gn_in_nparts, gn_in_groups, gn_in_silu;
+    float gn_in_eps;
     const float* gn_out_gamma; /* [N] or NULL */
     const float* gn_out_beta;  /* [N] */
     float gn_out_eps;
@@ -274,6 +286,8 @@ int imd_attention_fp8(const imd_attn_params* p, int eq, int ek, int ev, void* st
  *         at position 32 ((k >> 3) & 1) + 8 ((k >> 4) & 3) + (k & 7) (the order the kernel's packed P comes out in). */
 int imd_attn_quantize_fp8(const uint16_t* src, uint8_t* dst, int kind, long count, int LP, int exp2_scale, float pad_val, int dtype,
                           void* stream);
+/* 1 iff tile config cfg (12 / 13 / 14: the row-resident projections) can normalise its input rows as *p's gn_in_* fields ask */
+int imd_row_linear_gn_in_supported(const imd_conv_gemm_params* p, int cfg);
 /* 1 iff the finish launch of *p (split_k filled in as imd_conv_gemm will see it) can apply GroupNorm(gn_out_groups) (+ SiLU) to its output */
 int imd_conv_gemm_gn_out_supported(const imd_conv_gemm_params* p);
 /* 1 iff imd_attention accepts imd_attn_params.out_dup for this head count / query count / head dim (with k_pad_one = 1) */

@@ -55,7 +55,7 @@ def golden_legacy():
     return torch.load(os.path.join(GOLDEN, "processors_legacy.pt"), weights_only=False)
 
 
-_KNOB_NAMES = ("PATCH_CONV", "SPLITK_IN_KERNEL", "FUSED_FF", "FUSED_GN_STATS", "CFG_PAIR_DEDUP", "CFG_PAIR_ATTN", "FUSED_GN_FINISH", "FUSED_GN_CONV", "FUSED_LN", "FUSED_OUT_PROJ", "ATTN_FP8")
+_KNOB_NAMES = ("PATCH_CONV", "SPLITK_IN_KERNEL", "FUSED_FF", "FUSED_GN_STATS", "CFG_PAIR_DEDUP", "CFG_PAIR_ATTN", "FUSED_GN_FINISH", "FUSED_GN_CONV", "FUSED_GN_PROJ", "FUSED_LN", "FUSED_OUT_PROJ", "ATTN_FP8")
 
 
 @pytest.fixture(autouse=True)

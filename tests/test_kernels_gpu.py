@@ -250,6 +250,62 @@ def test_row_linear_k1280_layernorm_head_split(ops, dt):
     assert_close(q[..., :D], ref, atol=2e-2 if dt == bf16 else None, what="LN + to_q head split k1280")
 
 
+@pytest.mark.parametrize("B,H,W,Cc,G,producer,cfg", [
+    (8, 64, 64, 320, 32, "patch", 12),     # 64x64 level of the bench batch: statistics from the halo-patch conv's epilogue (96 partials per image), row_linear.hip
+    (3, 32, 32, 640, 32, "patch", 13),     # 32x32 level, row_linear_k640.hip
+    (8, 16, 16, 1280, 32, "finish", 14),   # 16x16 level: statistics from the split-K finish launch, row_linear_k1280.hip
+    (2, 16, 16, 320, 32, "pass", 12),      # statistics from an ordinary statistics pass (gn_stats_kernel's chunking), 256 rows per image
+    (3, 8, 8, 1280, 32, "pass", 14),       # 8x8 maps: 64 rows per image = exactly one row block of the K = 1280 kernel
+    (2, 8, 8, 640, 32, "pass", -1),        # 64 rows per image: not a multiple of the K = 640 kernel's 128-row block -> the wrapper runs the two launches
+])
+@pytest.mark.parametrize("silu", [False, True])
+@DTS
+def test_row_linear_groupnorm_of_the_input(ops, B, H, W, Cc, G, producer, cfg, silu, dt):
+    """imd_conv_gemm_params.gn_in_* (ABI v9): Transformer2DModel.norm -> proj_in as ONE launch of the row-resident projection kernels -- every workgroup
+    folds the statistic partials of its image in imd_groupnorm's own order and normalises its rows in registers.  BIT-IDENTICAL to imd_groupnorm followed
+    by the same projection (same coefficients, same rounding of the normalised value to the element type), whoever produced the statistics: a halo-patch
+    conv's epilogue, a split-K finish launch, or a statistics pass.  Shapes the kernels do not take fall back to the two launches inside the wrapper."""
+    from imagdressing_amd import ops as ops_mod
+    assert ops_mod.FUSED_GN_PROJ
+    gamma = 1.0 + 0.2 * rnd(6, Cc); beta = 0.2 * rnd(7, Cc)
+    w = rnd(8, Cc, Cc, scale=Cc ** -0.5).to(dt); b = rnd(9, Cc)
+    if producer == "pass":
+        x = dev((rnd(1, B, H, W, Cc) * 1.5 + 0.3).to(dt))
+        # a statistics pass writes its partials into the shared workspace: hand them over the way a producer would
+        a_, b_ = ops.group_norm_coeffs(x, dev(gamma), dev(beta), groups=G, eps=1e-6)       # (runs gn_stats_kernel: partials now sit in the workspace)
+        lib = ops.L.load()
+        nws = lib.imd_groupnorm_workspace_floats(B, H * W, Cc, G)
+        part = ops.workspace("gn_partial", (max(nws, 1),), torch.float32, x.device)
+        # chunks per image as norm.hip computes them: the workspace holds [B][nchunks][G][2] partials followed by 2 B C coefficient floats
+        nchunks = (nws - 2 * B * Cc) // (B * G * 2)
+        assert nchunks >= 1 and nchunks * B * G * 2 + 2 * B * Cc == nws
+        x._imd_gn_stats = (part[: B * nchunks * G * 2].view(B, nchunks, G, 2).clone(), nchunks, G)
+    else:
+        xin = dev(rnd(1, B, H, W, Cc).to(dt))
+        wc = rnd(2, Cc, Cc, 3, 3, scale=(9 * Cc) ** -0.5).to(dt)
+        kw = dict(cfg=5, split_k=1) if producer == "patch" else dict(cfg=5, split_k=4)     # (cfg of the PRODUCING conv)
+        x = ops.conv2d_nhwc(xin, dev(pack_conv(wc)), dev(rnd(3, Cc)), gn_stats_groups=G, **kw)
+        assert getattr(x, "_imd_gn_stats", None) is not None
+    two = ops.conv2d_nhwc(ops.group_norm(x, dev(gamma), dev(beta), groups=G, eps=1e-6, silu=silu), dev(w), dev(b), taps=1)
+    seen = []
+    hook = ops_mod.GEMM_EVENT_HOOK
+    ops_mod.GEMM_EVENT_HOOK = {}
+    try:
+        one = ops.conv2d_nhwc(x, dev(w), dev(b), taps=1, cfg=cfg, gn_in=(dev(gamma), dev(beta), 1e-6, silu, G))
+        seen = list(ops_mod.GEMM_EVENT_HOOK)
+    finally:
+        ops_mod.GEMM_EVENT_HOOK = hook
+    if cfg >= 0:
+        assert len(seen) == 1 and seen[0][1] == cfg, f"expected one row-resident launch, got {seen}"
+        two = ops.conv2d_nhwc(ops.group_norm(x, dev(gamma), dev(beta), groups=G, eps=1e-6, silu=silu), dev(w), dev(b), taps=1, cfg=cfg)
+    assert torch.equal(one, two), (one.float() - two.float()).abs().max().item()
+    ref = F.group_norm(x.float().cpu().permute(0, 3, 1, 2), G, gamma, beta, eps=1e-6)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1) @ w.float().t() + b
+    assert_close(one, ref, atol=4 * TOL[dt], what="GroupNorm inside the projection vs fp32")
+    ops_mod.FUSED_GN_PROJ = False               # the A/B switch restores the two launches (same values)
+    assert torch.equal(ops.conv2d_nhwc(x, dev(w), dev(b), taps=1, cfg=cfg, gn_in=(dev(gamma), dev(beta), 1e-6, silu, G)), two)
+
+
 @pytest.mark.parametrize("ln", [False, True])
 @DTS
 def test_row_qkv(ops, ln, dt):
