@@ -164,6 +164,10 @@ FUSED_GN_CONV = _os.environ.get("IMD_FUSED_GN_CONV", "0") == "1"
 FUSED_GN_FINISH = _os.environ.get("IMD_FUSED_GN_FINISH", "0") == "1"
 # (round 6) Transformer2DModel.norm inside proj_in's row-resident launch (gn_in_*): the normalised tensor never exists in memory (A/B switch)
 FUSED_GN_PROJ = _os.environ.get("IMD_FUSED_GN_PROJ", "1") != "0"
+# ... on which row-resident kernels (A/B): the prologue costs 6-8 us per launch in the running loop (profiles/r6final_kernel_trace_summary.md) -- less than the 10.3 us
+# gn_apply launch it replaces at the 64x64 level (tile config 12), about what the 5.4 / 4.3 us launches of the 32x32 / 16x16 levels (13 / 14) cost WITH their launch
+# boundary: all levels vs the 64x64 level only measured 593.0 vs 593.0 ms over four pairs (profiles/r6n_*) -> all levels (fewer launches, fewer bytes)
+FUSED_GN_PROJ_CFGS = tuple(int(c) for c in _os.environ.get("IMD_FUSED_GN_PROJ_CFGS", "12,13,14").split(",") if c)
 CFG_PAIR_ATTN = _os.environ.get("IMD_CFG_PAIR_ATTN", "1") != "0"     # ... and the first hybrid block up to its self-attention phase (unet.Transformer2D.call_pair_half; A/B switch)
 FUSED_LN = True            # engines hand `LayerNorm -> attn2.to_q` on 320 channels to the row-resident kernel as ONE launch (A/B switch)
 GEMM_TRACE = None          # tools/gemm_tune.py sets this to a list to record the shapes a forward pass launches
@@ -381,7 +385,7 @@ def conv_gemm(
         gi_gamma, gi_beta, gi_eps, gi_silu, gi_groups = gn_in
         st = getattr(x, "_imd_gn_stats", None)
         fused = False
-        if FUSED_GN_PROJ and cfg in (12, 13, 14) and st is not None and st[2] == gi_groups and FUSED_GN_STATS and st[0].shape[0] * Hout * Wout == M:
+        if FUSED_GN_PROJ and cfg in FUSED_GN_PROJ_CFGS and st is not None and st[2] == gi_groups and FUSED_GN_STATS and st[0].shape[0] * Hout * Wout == M:
             p.gn_in_partial, p.gn_in_nparts, p.gn_in_groups = st[0].data_ptr(), st[1], int(gi_groups)
             p.gn_in_gamma, p.gn_in_beta = _dev(gi_gamma, torch.float32, "gn_in gamma"), _dev(gi_beta, torch.float32, "gn_in beta")
             p.gn_in_eps, p.gn_in_silu = float(gi_eps), int(bool(gi_silu))
