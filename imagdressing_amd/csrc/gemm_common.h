@@ -64,8 +64,40 @@ __device__ __forceinline__ void xcd_tile_order(int flags, int m_tiles, int n_til
 // gn_apply_kernel (norm.hip, 320 threads: group = tid % G, every (320 / G)-th partial each, then a serial sum over the 320 / G lanes) folds them, so
 // that the fused launch is bit-identical to imd_groupnorm + the projection.  All threads of the workgroup call it (three barriers inside).
 // scratch: 2 * 320 + 128 + 2 * K floats.  Returns the coefficient arrays through a / sh.
+// Two halves so that the requests go out AHEAD of the kernel's activation loads and come back first (loads return in order): gn_in_request at the very
+// top of the kernel, gn_in_coeffs once the activations have been requested too -- the fold then waits for the partials only.
+constexpr int GN_IN_MAXP = 13;            // partials per thread requested as one burst (the usual 96 .. 128 partials per image are 10 .. 13 per thread)
 template <int K>
-__device__ __forceinline__ void gn_in_coeffs(const ConvGemmParams& p, int b, float* scratch, const float*& a, const float*& sh) {
+struct GnInReq {
+    float2 pv[GN_IN_MAXP];
+    float gam[(K + 511) / 512], bet[(K + 511) / 512];      // gamma / beta of channels tid, tid + 512, ... (512-thread workgroups)
+    bool burst;
+};
+
+template <int K>
+__device__ __forceinline__ void gn_in_request(const ConvGemmParams& p, int b, GnInReq<K>& r) {
+    constexpr int T = 320;
+    const int tid = threadIdx.x;
+    const int Gn = p.gn_in_groups, nchunks = p.gn_in_nparts;
+    const int parts = T / Gn;
+    const int g = tid % Gn, part = tid / Gn;
+    r.burst = nchunks <= GN_IN_MAXP * parts;
+#pragma unroll
+    for (int i = 0; i < GN_IN_MAXP; ++i) {
+        const int c = part + i * parts;
+        r.pv[i] = (r.burst && tid < T && part < parts && c < nchunks) ? *reinterpret_cast<const float2*>(p.gn_in_partial + (((size_t)b * nchunks + c) * Gn + g) * 2)
+                                                                          : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < (K + 511) / 512; ++i) {
+        const int c = tid + 512 * i;
+        r.gam[i] = c < K ? p.gn_in_gamma[c] : 0.f;
+        r.bet[i] = c < K ? p.gn_in_beta[c] : 0.f;
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void gn_in_coeffs(const ConvGemmParams& p, int b, const GnInReq<K>& r, float* scratch, const float*& a, const float*& sh) {
     constexpr int T = 320;
     float* red_s = scratch;
     float* red_q = scratch + T;
@@ -79,20 +111,13 @@ __device__ __forceinline__ void gn_in_coeffs(const ConvGemmParams& p, int b, flo
         const int parts = T / Gn;
         const int g = tid % Gn, part = tid / Gn;
         float S = 0.f, Q = 0.f;
-        // a thread's partials are requested TOGETHER (up to MAXP of them; the usual 96 .. 128 per image are 10 .. 13 per thread) and summed in the same
-        // ascending order afterwards: as a run-time loop the fold is a chain of ~10 dependent trips to the L2 that every workgroup of the launch waits out
-        constexpr int MAXP = 13;
-        if (nchunks <= MAXP * parts) {
-            float2 pv[MAXP];
+        // the partials were requested TOGETHER (gn_in_request) and are summed in the same ascending order: as a run-time loop the fold is a chain of ~10
+        // dependent trips to the L2 that every workgroup of the launch waits out
+        if (r.burst) {
 #pragma unroll
-            for (int i = 0; i < MAXP; ++i) {
+            for (int i = 0; i < GN_IN_MAXP; ++i) {
                 const int c = part + i * parts;
-                pv[i] = (part < parts && c < nchunks) ? *reinterpret_cast<const float2*>(p.gn_in_partial + (((size_t)b * nchunks + c) * Gn + g) * 2) : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < MAXP; ++i) {
-                const int c = part + i * parts;
-                if (part < parts && c < nchunks) { S += pv[i].x; Q += pv[i].y; }
+                if (part < parts && c < nchunks) { S += r.pv[i].x; Q += r.pv[i].y; }
             }
         } else if (part < parts) {
             for (int c = part; c < nchunks; c += parts) {
@@ -114,11 +139,15 @@ __device__ __forceinline__ void gn_in_coeffs(const ConvGemmParams& p, int b, flo
         s_rstd[tid] = rsqrtf(var + p.gn_in_eps);
     }
     __syncthreads();
-    for (int c = tid; c < K; c += (int)blockDim.x) {
-        const int g = c / cpg;
-        const float ga = p.gn_in_gamma[c] * s_rstd[g];
-        s_a[c] = ga;
-        s_sh[c] = p.gn_in_beta[c] - s_mean[g] * ga;
+#pragma unroll
+    for (int i = 0; i < (K + 511) / 512; ++i) {
+        const int c = tid + 512 * i;
+        if (c < K) {
+            const int g = c / cpg;
+            const float ga = r.gam[i] * s_rstd[g];
+            s_a[c] = ga;
+            s_sh[c] = r.bet[i] - s_mean[g] * ga;
+        }
     }
     __syncthreads();
     a = s_a; sh = s_sh;

@@ -55,6 +55,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     const int chh = wave >> 2;          // which 32-channel half of every 64-channel weight chunk
     const int m0 = blockIdx.x * RL_BM;
 
+    GnInReq<RL_K> gnreq;
+    if constexpr (GN) gn_in_request<RL_K>(p, m0 / (p.Hout * p.Wout), gnreq);      // (ahead of the activation loads: they come back first)
     // ---- activations: this wave's 32 rows, all of K, straight into B-operand fragments ----
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const int m = m0 + rb * 32 + col;
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     if constexpr (GN) {      // rows normalised in place with the per-channel coefficients of this workgroup's image (its 128 rows lie in ONE image)
         // scratch = ring slot 2: no DMA piece lands there before stage(2), which is issued behind the first barrier of the chunk loop
         const float *ga, *gs;
-        gn_in_coeffs<RL_K>(p, m0 / (p.Hout * p.Wout), reinterpret_cast<float*>(smem + 2 * RL_CHUNK), ga, gs);
+        gn_in_coeffs<RL_K>(p, m0 / (p.Hout * p.Wout), gnreq, reinterpret_cast<float*>(smem + 2 * RL_CHUNK), ga, gs);
         const bool silu = p.gn_in_silu != 0;
 #pragma unroll
         for (int s = 0; s < RL_STEPS; ++s) {       // (one fragment at a time: left alone hipcc hoists all 80 coefficient reads and spills 190 registers)

@@ -64,6 +64,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
     if (mblk * 64 >= p.M) return;
     const int m0 = mblk * 64 + tb * 32, n0 = grp * R12_NG;
 
+    GnInReq<R12_K> gnreq;
+    if constexpr (GN) gn_in_request<R12_K>(p, (mblk * 64) / (p.Hout * p.Wout), gnreq);      // (ahead of the activation loads: they come back first)
     // ---- activations: 2 x 16 rows x 320 k (this wave's K quarter) straight into B-operand fragments ----
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     uint4 xf[2][R12_STEPS];
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_k1280_kernel(const ConvGemm
 
     if constexpr (GN) {      // (scratch = ring slot 2: nothing lands there before stage(2), issued behind the chunk loop's first barrier; the 64 rows lie in ONE image)
         const float *ga, *gs;
-        gn_in_coeffs<R12_K>(p, (mblk * 64) / (p.Hout * p.Wout), reinterpret_cast<float*>(smem + 2 * R12_CHUNK), ga, gs);
+        gn_in_coeffs<R12_K>(p, (mblk * 64) / (p.Hout * p.Wout), gnreq, reinterpret_cast<float*>(smem + 2 * R12_CHUNK), ga, gs);
         const bool silu = p.gn_in_silu != 0;
 #pragma unroll
         for (int th = 0; th < 2; ++th)

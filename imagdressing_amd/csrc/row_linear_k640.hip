@@ -53,6 +53,8 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
     const int m0 = mblk * 128, n0 = grp * R6_NG;
     const int m = m0 + tb * 32 + col;
 
+    GnInReq<R6_K> gnreq;
+    if constexpr (GN) gn_in_request<R6_K>(p, m0 / (p.Hout * p.Wout), gnreq);      // (ahead of the activation loads: they come back first)
     // ---- activations: 32 rows x 320 k (this wave's K half) straight into B-operand fragments ----
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const uint32_t xoff = (uint32_t)m * (uint32_t)(p.x_pix_stride * 2) + (uint32_t)(kh * (R6_KH * 2) + hi * 16);
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(512, 1) void row_linear_k640_kernel(const ConvGemmP
 
     if constexpr (GN) {      // (scratch = ring slot 2: nothing lands there before stage(2), issued behind the chunk loop's first barrier)
         const float *ga, *gs;
-        gn_in_coeffs<R6_K>(p, m0 / (p.Hout * p.Wout), reinterpret_cast<float*>(smem + 2 * R6_CHUNK), ga, gs);
+        gn_in_coeffs<R6_K>(p, m0 / (p.Hout * p.Wout), gnreq, reinterpret_cast<float*>(smem + 2 * R6_CHUNK), ga, gs);
         const bool silu = p.gn_in_silu != 0;
 #pragma unroll
         for (int s = 0; s < R6_STEPS; ++s) {       // (one fragment at a time: see row_linear.hip)
