@@ -389,7 +389,16 @@ def main():
         # roofline hook: bracket every level-0 hybrid-attention launch of the timed region with HIP events
         # (B == 2 * batch: the launch attn_flops_hybrid_level0 prices -- `batch` two-phase + `batch` one-phase rows.  The first hybrid block of a
         # step runs the cond rows only with its first phase stored twice (round 6, imd_attn_params.out_dup): fewer FLOPs, not this launch.)
-        hook = {"match": lambda B, H, N, D, L1, L2: D == 40 and N == N0 and L2 == N0 and B == 2 * batch, "events": []}
+        # (round 6) every FOURTH such launch is bracketed (50 of the 200 per bench step): an event pair between two kernels costs the stream ~6 us in front of
+        # the launch and ~1.5 us behind it (tools/rocprof_sequence.py, profiles/r6r_*: 47 us of gaps per DDIM step with every launch bracketed)
+        seen_l0 = [0]
+
+        def match_l0(B, H, N, D, L1, L2):
+            if not (D == 40 and N == N0 and L2 == N0 and B == 2 * batch):
+                return False
+            seen_l0[0] += 1
+            return seen_l0[0] % 4 == 0
+        hook = {"match": match_l0, "events": []}
         if hook_attention and not graph:
             ops.ATTN_EVENT_HOOK = hook
         barrier()
