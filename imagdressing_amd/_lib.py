@@ -139,6 +139,9 @@ SYMBOLS = {
     "imd_lincomb": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     "imd_copy2d": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_void_p]),
     "imd_concat2": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_long, C.c_int, C.c_void_p]),
+    "imd_concat2_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_void_p]),
+    "imd_groupnorm_parts": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "imd_f32_to_16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p]),
 }
 

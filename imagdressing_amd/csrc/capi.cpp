@@ -282,6 +282,14 @@ int imd_concat2(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint
     return imd_launch_concat2(a, Ca, b, Cb, b_add, out, rows, b_rows, dtype, (hipStream_t)stream);
 }
 
+int imd_groupnorm_parts(int B, int HW, int C) { return imd_groupnorm_parts_of(B, HW, C); }
+
+int imd_concat2_gn_stats(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint16_t* b_add, uint16_t* out, int B, int HW, int b_B, int G,
+                         float* partial, int dtype, void* stream) {
+    IMD_REQUIRE(a && b && out && partial, "concat2 + statistics: null pointer");
+    return imd_launch_concat2_gn_stats(a, Ca, b, Cb, b_add, out, B, HW, b_B, G, partial, dtype, (hipStream_t)stream);
+}
+
 int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream) {
     IMD_REQUIRE(a && out, "f32_to_16: null pointer");
     return imd_launch_f32_to_16(a, out, n, dtype, (hipStream_t)stream);

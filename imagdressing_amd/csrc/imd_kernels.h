@@ -73,6 +73,9 @@ int imd_attn_dpk(int D);
 int imd_attn_dpv(int D);
 int imd_launch_groupnorm(const GroupNormParams& p, hipStream_t s);
 int imd_launch_groupnorm_coeffs(const GroupNormParams& p, float* ca, float* cb, hipStream_t s);
+int imd_groupnorm_parts_of(int B, int HW, int C);
+int imd_launch_concat2_gn_stats(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, int B, int HW, int b_B, int G,
+                                float* partial, int dtype, hipStream_t s);
 int imd_launch_layernorm(const LayerNormParams& p, hipStream_t s);
 int imd_launch_softmax_rows(const float* s_in, int s_ld, bf16_t* p_out, int p_ld, int rows, int cols, int dtype, hipStream_t s);
 int imd_launch_ddim_cfg_step(const DdimParams& p, hipStream_t s);

@@ -113,6 +113,94 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(const GroupNormPar
     }
 }
 
+// gn_stats_kernel over out = cat([a, b (+ b_add)], channel), WRITING out on the way (round 6): the skip concatenation of an up block and the
+// statistics pass of the ResnetBlock2D.norm1 that follows it were two sweeps over the same tensor.  Same chunking, same thread -> (vector
+// column, pixel lane) map and same summation order as gn_stats_kernel on the finished tensor, and the sums are taken from the ROUNDED 16-bit
+// values that are stored: partials bit-identical to the two-launch form.  b may hold B / k images (one skip tensor for both CFG halves).
+struct ConcatSrc { const bf16_t* a; int Ca; const bf16_t* b; int Cb; const bf16_t* b_add; int b_B; };
+
+template <bool F16>
+__global__ __launch_bounds__(GN_THREADS) void concat2_stats_kernel(const GroupNormParams p, const ConcatSrc q) {
+    __shared__ float red[GN_THREADS][4];
+    const int vpp = p.C / 8;
+    const int tid = threadIdx.x;
+    const int cpg = p.C / p.G;
+    const int chunk = blockIdx.x, b = blockIdx.y;
+    const int ppc = gn_pix_per_chunk(p.B, p.HW, p.C);
+    const int pix0 = chunk * ppc;
+    const int pix1 = min(p.HW, pix0 + ppc);
+    const int nchunks = gn_chunks(p.B, p.HW, p.C);
+    const int cols = min(vpp, GN_THREADS);
+    const int plan = GN_THREADS / cols;
+    const int my_col = tid % cols, my_pl = tid / cols;
+    const bool active = my_pl < plan;
+
+    for (int cbase = 0; cbase < vpp; cbase += cols) {
+        const int vec = cbase + my_col;
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        const int c0 = vec * 8;
+        const int g0 = c0 / cpg;
+        const int split = min(8, (g0 + 1) * cpg - c0);
+        if (active && vec < vpp) {
+            const bool from_a = c0 < q.Ca;
+            const int cs = from_a ? c0 : c0 - q.Ca;
+            const int ld = from_a ? q.Ca : q.Cb;
+            const bf16_t* src = from_a ? q.a + (size_t)b * p.HW * q.Ca + cs : q.b + (size_t)(b % q.b_B) * p.HW * q.Cb + cs;
+            const bf16_t* add = (!from_a && q.b_add) ? q.b_add + (size_t)b * p.HW * q.Cb + cs : nullptr;
+            bf16_t* ob = p.y + (size_t)b * p.HW * p.C + c0;
+            for (int pix = pix0 + my_pl; pix < pix1; pix += 4 * plan) {
+                uint4 v[4], w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int px = pix + u * plan;
+                    v[u] = (px < pix1) ? *reinterpret_cast<const uint4*>(src + (size_t)px * ld) : make_uint4(0, 0, 0, 0);
+                    if (add) w[u] = (px < pix1) ? *reinterpret_cast<const uint4*>(add + (size_t)px * ld) : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int px = pix + u * plan;
+                    float f[8];
+                    if (add) {       // (the ControlNet residual: summed in fp32, rounded once -- concat2_kernel's arithmetic)
+                        float x[8], y[8];
+                        unpack8<F16>(v[u], x);
+                        unpack8<F16>(w[u], y);
+                        v[u] = make_uint4(El<F16>::pack2(x[0] + y[0], x[1] + y[1]), El<F16>::pack2(x[2] + y[2], x[3] + y[3]),
+                                          El<F16>::pack2(x[4] + y[4], x[5] + y[5]), El<F16>::pack2(x[6] + y[6], x[7] + y[7]));
+                    }
+                    if (px < pix1) *reinterpret_cast<uint4*>(ob + (size_t)px * p.C) = v[u];
+                    unpack8<F16>(v[u], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
+                        else           { s1 += f[e]; q1 += f[e] * f[e]; }
+                    }
+                }
+            }
+        }
+        red[tid][0] = s0; red[tid][1] = q0; red[tid][2] = s1; red[tid][3] = q1;
+        __syncthreads();
+        if (tid < p.G) {
+            const int g = tid;
+            const int cfirst = g * cpg, clast = (g + 1) * cpg - 1;
+            int vlo = cfirst / 8, vhi = clast / 8;
+            vlo = max(vlo, cbase); vhi = min(vhi, min(vpp, cbase + cols) - 1);
+            float S = 0.f, Q = 0.f;
+            for (int v = vlo; v <= vhi; ++v) {
+                const int vg0 = (v * 8) / cpg;
+                for (int pl = 0; pl < plan; ++pl) {
+                    const float* e = red[pl * cols + (v - cbase)];
+                    if (vg0 == g) { S += e[0]; Q += e[1]; }
+                    else if (vg0 + 1 == g) { S += e[2]; Q += e[3]; }
+                }
+            }
+            float* dst = p.partial + (((size_t)b * nchunks + chunk) * p.G + g) * 2;
+            if (cbase == 0) { dst[0] = S; dst[1] = Q; }
+            else { dst[0] += S; dst[1] += Q; }
+        }
+        __syncthreads();
+    }
+}
+
 template <bool F16>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(const GroupNormParams p) {
     __shared__ float s_mean[64], s_rstd[64];
@@ -416,6 +504,28 @@ static int gn_validate(const GroupNormParams& p) {
     if (p.x_ld % 8 || p.y_ld % 8) return imd_set_error("groupnorm: pixel strides must be multiples of 8");
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("groupnorm: unknown dtype %d", p.dtype);
     return 0;
+}
+
+int imd_groupnorm_parts_of(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0 || C % 8) return 0;
+    return gn_chunks(B, HW, C);
+}
+
+int imd_launch_concat2_gn_stats(const bf16_t* a, int Ca, const bf16_t* b, int Cb, const bf16_t* b_add, bf16_t* out, int B, int HW, int b_B, int G,
+                                float* partial, int dtype, hipStream_t s) {
+    if (Ca <= 0 || Cb <= 0 || Ca % 8 || Cb % 8) return imd_set_error("concat2 + statistics: channel counts must be positive multiples of 8 (got %d + %d)", Ca, Cb);
+    if (b_B <= 0 || B % b_B) return imd_set_error("concat2 + statistics: b holds %d images, which must divide B = %d", b_B, B);
+    GroupNormParams p{};
+    p.y = out; p.partial = partial;
+    p.B = B; p.HW = HW; p.C = Ca + Cb; p.G = G; p.x_ld = p.y_ld = Ca + Cb; p.dtype = dtype;
+    if (G <= 0) return imd_set_error("concat2 + statistics: G must be positive");
+    int rc = gn_validate(p);
+    if (rc) return rc;
+    const ConcatSrc q{a, Ca, b, Cb, b_add, b_B};
+    dim3 grid(gn_chunks(B, HW, p.C), B);
+    if (dtype == IMD_DTYPE_F16) hipLaunchKernelGGL(concat2_stats_kernel<true>, grid, dim3(GN_THREADS), 0, s, p, q);
+    else hipLaunchKernelGGL(concat2_stats_kernel<false>, grid, dim3(GN_THREADS), 0, s, p, q);
+    return imd_check_launch("concat2 + groupnorm statistics");
 }
 
 int imd_launch_groupnorm_coeffs(const GroupNormParams& p, float* ca, float* cb, hipStream_t s) {

@@ -164,6 +164,8 @@ FUSED_GN_CONV = _os.environ.get("IMD_FUSED_GN_CONV", "0") == "1"
 FUSED_GN_FINISH = _os.environ.get("IMD_FUSED_GN_FINISH", "0") == "1"
 # (round 6) Transformer2DModel.norm inside proj_in's row-resident launch (gn_in_*): the normalised tensor never exists in memory (A/B switch)
 FUSED_GN_PROJ = _os.environ.get("IMD_FUSED_GN_PROJ", "1") != "0"
+# (round 6) the skip concatenation of an up block also writes the GroupNorm statistics of its output: norm1 of the resnet behind it skips its statistics launch (A/B switch)
+FUSED_CONCAT_STATS = _os.environ.get("IMD_FUSED_CONCAT_STATS", "1") != "0"
 # ... on which row-resident kernels (A/B): the prologue costs 6-8 us per launch in the running loop (profiles/r6final_kernel_trace_summary.md) -- less than the 10.3 us
 # gn_apply launch it replaces at the 64x64 level (tile config 12), about what the 5.4 / 4.3 us launches of the 32x32 / 16x16 levels (13 / 14) cost WITH their launch
 # boundary: all levels vs the 64x64 level only measured 593.0 vs 593.0 ms over four pairs (profiles/r6n_*) -> all levels (fewer launches, fewer bytes)
@@ -863,8 +865,12 @@ def add(a: torch.Tensor, b: torch.Tensor, b_scale: float = 1.0, out=None) -> tor
     return out
 
 
-def concat_channels(a: torch.Tensor, b: torch.Tensor, b_add: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """cat([a, b (+ b_add)], channel) for NHWC tensors [..., Ca] and [..., Cb]."""
+def concat_channels(a: torch.Tensor, b: torch.Tensor, b_add: Optional[torch.Tensor] = None, gn_stats_groups: int = 0) -> torch.Tensor:
+    """cat([a, b (+ b_add)], channel) for NHWC tensors [..., Ca] and [..., Cb].
+
+    ``gn_stats_groups`` = G (4-D operands [B, H, W, C]): the launch also writes the GroupNorm(G) statistics of its output, which ride on the
+    returned tensor (``_imd_gn_stats``) exactly as a convolution's do -- the :func:`group_norm` behind an up block's concatenation then
+    normalises only.  Same partials as the statistics launch would write (same chunking and order): bit-identical either way."""
     ensure_device(a.device)
     Ca, Cb = a.shape[-1], b.shape[-1]
     rows = a.numel() // Ca
@@ -874,6 +880,18 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor, b_add: Optional[torch.Tens
     b_rows = b.numel() // Cb            # b may hold HALF the rows: one skip tensor for both (identical) halves of a CFG batch
     if b_rows * Cb != b.numel() or b_rows == 0 or rows % b_rows or (b_add is not None and b_add.numel() != rows * Cb):
         raise L.ImdError(f"concat_channels: operands disagree on the row count ({rows} rows of {Ca} + {Cb} channels, b has {b_rows})")
+    G = gn_stats_groups
+    if G and FUSED_CONCAT_STATS and FUSED_GN_STATS and a.dim() == 4 and b.dim() == 4 and (Ca + Cb) % G == 0:
+        B = a.shape[0]
+        HW = rows // B
+        cpg = (Ca + Cb) // G
+        nparts = lib.imd_groupnorm_parts(B, HW, Ca + Cb)
+        if nparts > 0 and b_rows % HW == 0 and G <= 64 and (cpg >= 8 or cpg == 4):
+            part = torch.empty((B, nparts, G, 2), dtype=torch.float32, device=a.device)
+            L.check(lib.imd_concat2_gn_stats(_dev(a, dt, "a"), Ca, _dev(b, dt, "b"), Cb, _opt(b_add, dt, "b_add"), out.data_ptr(), B, HW, b_rows // HW, G,
+                                             part.data_ptr(), _code(a, "a"), _stream()))
+            out._imd_gn_stats = (part, nparts, G)
+            return out
     L.check(lib.imd_concat2(_dev(a, dt, "a"), Ca, _dev(b, dt, "b"), Cb, _opt(b_add, dt, "b_add"), out.data_ptr(), rows, b_rows, _code(a, "a"), _stream()))
     return out
 

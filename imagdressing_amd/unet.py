@@ -585,7 +585,7 @@ class UNet2DConditionModel(_Encoder):
             for j, r in enumerate(blk.resnets):
                 s = skips.pop()
                 c = None if ctrl is None else ctrl[len(skips)]
-                h = ops.concat_channels(h, s, c)          # cat([x, skip (+ ControlNet residual)])
+                h = ops.concat_channels(h, s, c, gn_stats_groups=r.groups)          # cat([x, skip (+ ControlNet residual)]) + the statistics of the resnet's norm1
                 h = r(h, temb_all)
                 if blk.attentions:
                     h = blk.attentions[j](h, ehs, cak)

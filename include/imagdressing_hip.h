@@ -385,6 +385,15 @@ int imd_copy2d(const uint16_t* a, int a_ld, uint16_t* out, int out_ld, long rows
  * b_rows: 0 (= rows), or a divisor of rows -- b then holds b_rows rows and row r reads b[r % b_rows] (one skip tensor serving both
  * halves of a CFG batch whose halves are identical up to that layer). */
 int imd_concat2(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint16_t* b_add, uint16_t* out, long rows, long b_rows, int dtype, void* stream);
+/* imd_concat2 over B images of HW pixels that ALSO writes the GroupNorm(G) statistics of its output -- the ResnetBlock2D.norm1 that
+ * follows every skip concatenation of the up path (diffusers unet_2d_blocks.py CrossAttnUpBlock2D / UpBlock2D.forward: cat, then resnet) --
+ * as partial[B][imd_groupnorm_parts(B, HW, Ca + Cb)][G][2] fp32 (sum, sum of squares), the layout imd_groupnorm_params.nparts takes.
+ * Same chunking and summation order as imd_groupnorm's own statistics launch on the finished tensor: bit-identical partials, one sweep
+ * less.  b holds b_B images (a divisor of B; image i reads b[i % b_B]). */
+int imd_concat2_gn_stats(const uint16_t* a, int Ca, const uint16_t* b, int Cb, const uint16_t* b_add, uint16_t* out, int B, int HW, int b_B, int G,
+                         float* partial, int dtype, void* stream);
+/* number of per-image statistic partials imd_groupnorm's own statistics launch (and imd_concat2_gn_stats) writes for this tensor; 0 if C % 8 */
+int imd_groupnorm_parts(int B, int HW, int C);
 /* fp32 -> 16-bit element cast (round to nearest even). */
 int imd_f32_to_16(const float* a, uint16_t* out, long n, int dtype, void* stream);
 

@@ -1246,6 +1246,34 @@ def test_ddim_cfg_step_stochastic(ops, inpaint, eta):
 
 
 @DTS
+@pytest.mark.parametrize("B,H,W,Ca,Cb,half,ctrl", [(4, 16, 16, 1280, 640, True, False), (2, 32, 32, 640, 320, False, True), (8, 64, 64, 320, 320, True, False),
+                                                 (2, 8, 8, 1280, 1280, False, False), (1, 20, 16, 640, 640, False, True), (2, 16, 16, 64, 64, False, False)])
+def test_concat_that_also_writes_the_groupnorm_statistics(ops, dt, monkeypatch, B, H, W, Ca, Cb, half, ctrl):
+    """The skip concatenation of an up block with the statistics of the resnet's norm1 behind it (imd_concat2_gn_stats): the concatenated
+    tensor is what imd_concat2 writes, and GroupNorm + SiLU of it with the statistics that ride on it is BIT-IDENTICAL to the two-launch
+    GroupNorm of the same tensor (same partials: same chunking, same order).  ``half``: the skip tensor holds one copy for both CFG halves;
+    ``ctrl``: a ControlNet residual is added to the skip."""
+    a = dev(rnd(1, B, H, W, Ca).to(dt))
+    b = dev((rnd(2, B // 2 if half else B, H, W, Cb) * 1.5 + 0.25).to(dt))
+    c = dev(rnd(3, B, H, W, Cb).to(dt)) if ctrl else None
+    gamma, beta = dev(rnd(4, Ca + Cb) * 0.2 + 1.0), dev(rnd(5, Ca + Cb) * 0.1)
+    plain = ops.concat_channels(a, b, c)
+    assert getattr(plain, "_imd_gn_stats", None) is None
+    fused = ops.concat_channels(a, b, c, gn_stats_groups=32)
+    st = getattr(fused, "_imd_gn_stats", None)
+    assert st is not None and st[2] == 32 and tuple(st[0].shape) == (B, st[1], 32, 2)
+    assert torch.equal(plain, fused)
+    want = ops.group_norm(plain, gamma, beta, groups=32, eps=1e-5, silu=True)          # statistics launch + normalise
+    got = ops.group_norm(fused, gamma, beta, groups=32, eps=1e-5, silu=True)           # normalise only
+    assert torch.equal(want, got)
+    ref = torch.nn.functional.silu(torch.nn.functional.group_norm(plain.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-5)).permute(0, 2, 3, 1)
+    assert_close(got, ref, what="groupnorm of the concatenation")
+    monkeypatch.setattr(ops, "FUSED_CONCAT_STATS", False)
+    off = ops.concat_channels(a, b, c, gn_stats_groups=32)
+    assert getattr(off, "_imd_gn_stats", None) is None and torch.equal(off, plain)
+
+
+@DTS
 def test_add_concat_cast(ops, dt):
     a = rnd(1, 2, 50, 320).to(dt); b = rnd(2, 2, 50, 640).to(dt); c = rnd(3, 2, 50, 640).to(dt)
     assert_close(ops.add(dev(b), dev(c), 0.5), b.float() + 0.5 * c.float(), what="add")
