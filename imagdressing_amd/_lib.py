@@ -47,7 +47,7 @@ class ConvGemmParams(_Sized):
         ("gn_stats_out", C.c_void_p), ("gn_stats_groups", C.c_int),
         ("gn_in_partial", C.c_void_p), ("gn_in_gamma", C.c_void_p), ("gn_in_beta", C.c_void_p),
         ("gn_in_nparts", C.c_int), ("gn_in_groups", C.c_int), ("gn_in_silu", C.c_int), ("gn_in_eps", C.c_float),
-        ("gn_out_gamma", C.c_void_p), ("gn_out_beta", C.c_void_p), ("gn_out_eps", C.c_float), ("gn_out_silu", C.c_int), ("gn_out_groups", C.c_int),
+        ("gn_out_gamma", C.c_void_p), ("gn_out_beta", C.c_void_p), ("gn_out_eps", C.c_float), ("gn_out_silu", C.c_int), ("gn_out_groups", C.c_int), ("res_rows", C.c_int),
     ]
 
 

@@ -229,7 +229,7 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
     block's UN-normalised hidden state and LayerNorm runs inside the Q projection (cross-attention, C = 320 only).
     ``pair_half`` (self-attention with a garment key set only): ``x`` holds the B cond rows of a CFG batch whose uncond rows have
     bit-identical hidden states; the result has 2B rows -- [0, B) the hybrid output, [B, 2B) the plain self-attention output of
-    the same rows (the attention launch stores its first phase twice, ``imd_attn_params.out_dup``) -- and ``residual`` has 2B rows."""
+    the same rows (the attention launch stores its first phase twice, ``imd_attn_params.out_dup``) -- and ``residual`` has 2B rows, or B (the same block input for both halves, one copy)."""
     B, N, Cc = x.shape
     D = Cc // heads
     dpk, dpv = ops.attn_padded_dims(D)
@@ -278,7 +278,8 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
         o = torch.empty(2 * B, N, Cc, dtype=dt, device=dev)
         ops.attention(q, kv1[0], kv1[1], o[:B], B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True,
                       out_dup=o[B:], **kw)
-        res2 = None if residual is None else residual.view(2 * B * N, Cc)
+        # (the residual may hold B or 2B rows: B = one copy for both halves, added periodically by the projection -- ops.conv_gemm)
+        res2 = None if residual is None else residual.reshape(-1, Cc)
         return ops.linear(o.view(2 * B * N, Cc), wo, bo, res=res2).view(2 * B, N, Cc)
     ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True, **kw)
     res2 = None if residual is None else residual.view(B * N, Cc)

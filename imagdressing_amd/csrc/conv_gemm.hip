@@ -711,6 +711,8 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("conv_gemm: unknown dtype %d", p.dtype);
     if ((p.gn_a != nullptr) != (p.gn_b != nullptr)) return imd_set_error("conv_gemm: gn_a and gn_b must be given together");
     if (p.gn_a != nullptr && cfg != 5) return imd_set_error("conv_gemm: the fused GroupNorm prologue needs tile config 5 (got %d)", cfg);
+    if (p.res_rows != 0 && cfg != 12)
+        return imd_set_error("conv_gemm: a periodic residual (res_rows = %d) exists in the K = 320 row-resident projection only (tile config 12, got %d)", p.res_rows, cfg);
     if (p.gn_in_partial != nullptr && !imd_row_linear_gn_in_supported_of(p, cfg))
         return imd_set_error("conv_gemm: gn_in_* (GroupNorm of the input rows) exists in the row-resident projections only (tile configs 12 / 13 / 14 with H W a multiple of "
                              "their row block; got cfg=%d K=%d HW=%d): ask imd_row_linear_gn_in_supported() first", cfg, p.K, p.Hout * p.Wout);

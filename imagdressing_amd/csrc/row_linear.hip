@@ -78,7 +78,9 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
     const bool has_res = DIRECT && !LN && !GN && p.res != nullptr;      // (LayerNorm + residual: staged epilogue)
     const bool heads = !GN && p.mode == OUT_HEADS;
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.res), 0, 0x80000000u, 0x00020000);
-    const uint32_t roff = (uint32_t)m * (uint32_t)(p.res_ld * 2) + (uint32_t)((wave >> 2) * 64);
+    // (periodic residual, res_rows > 0: row m adds res[m % res_rows]; res_rows is a multiple of the 128-row block, so the shift is per workgroup)
+    const int res_shift = p.res_rows > 0 ? (m0 / p.res_rows) * p.res_rows : 0;
+    const uint32_t roff = (uint32_t)(m - res_shift) * (uint32_t)(p.res_ld * 2) + (uint32_t)((wave >> 2) * 64);
     auto load_res = [&](int c) {        // residual of chunk c: lane = token; 8 consecutive channels per 16-byte load (wide; put into the accumulator layout
                                         // by emit), or 4 per 8-byte load in accumulator layout
 #pragma unroll
@@ -284,6 +286,11 @@ __global__ __launch_bounds__(512, 1) void row_linear_kernel(const ConvGemmParams
             const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * RL_CLD + cc);
             const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * RL_CLD + cc + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (p.res_rows > 0) {      // (staged form of the periodic residual: the same shared epilogue on a parameter block whose residual base is shifted)
+                ConvGemmParams q = p;
+                q.res = p.res - (size_t)res_shift * p.res_ld;
+                epilogue8<F16>(q, v, mm, cc, 8, HWo);
+            } else
             epilogue8<F16>(p, v, mm, cc, 8, HWo);
         }
     }
@@ -338,6 +345,8 @@ int imd_launch_row_linear(const ConvGemmParams& p_in, int ln, float ln_eps, hipS
         return imd_set_error("row_linear: needs a plain linear layer with K = 320 and N = 64..320 in steps of 64 (got N=%d K=%d taps=%d split=%d)", p.N, p.K, p.taps, p.split_k);
     if (p.gn_in_partial != nullptr && (ln || !gn_in_ok(p, RL_K, RL_BM)))
         return imd_set_error("row_linear: gn_in_* needs K = 320, K %% groups == 0, groups <= 64, H W %% 128 == 0 and no LayerNorm prologue (ask imd_row_linear_gn_in_supported())");
+    if (p.res_rows != 0 && (p.res == nullptr || p.res_rows < 0 || p.res_rows % RL_BM || p.M % p.res_rows))
+        return imd_set_error("row_linear: res_rows (%d) needs a residual, a multiple of %d rows and a divisor of M = %d", p.res_rows, RL_BM, p.M);
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("row_linear: unknown dtype %d", p.dtype);
     const size_t xb = ((size_t)(p.M - 1) * p.x_pix_stride + p.K) * 2, wb = (size_t)p.N * p.K * 2;
     if (xb >= 0xffffffffull) return imd_set_error("row_linear: operand larger than 4 GiB");

@@ -289,6 +289,7 @@ bool imd_row_linear_k1280_supported(const ConvGemmParams& p) {
 
 int imd_launch_row_linear_k1280(const ConvGemmParams& p_in, int ln, float ln_eps, hipStream_t s) {
     ConvGemmParams p = p_in;
+    if (p_in.res_rows != 0) return imd_set_error("row_linear_k1280: a periodic residual (res_rows) exists in the K = 320 row-resident projection only");
     if (!imd_row_linear_k1280_supported(p))
         return imd_set_error("row_linear_k1280: needs a plain linear layer with K = 1280, N a multiple of 160 and a bias / scale / residual epilogue "
                              "(got N=%d K=%d taps=%d act=%d)", p.N, p.K, p.taps, p.act);

@@ -206,6 +206,7 @@ bool imd_row_qkv_supported(const ConvGemmParams& p) {
 
 int imd_launch_row_qkv(const ConvGemmParams& p_in, int ln, float ln_eps, hipStream_t s) {
     ConvGemmParams p = p_in;
+    if (p_in.res_rows != 0) return imd_set_error("row_qkv: a periodic residual (res_rows) exists in the K = 320 row-resident projection only");
     if (!imd_row_qkv_supported(p)) return imd_set_error("row_qkv: needs the 320 -> 960 head-split q/k/v projection (Q, K row-major, V transposed), HW %% 128 == 0");
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("row_qkv: unknown dtype %d", p.dtype);
     const size_t xb = ((size_t)(p.M - 1) * p.x_pix_stride + p.K) * 2;

@@ -166,6 +166,8 @@ FUSED_GN_FINISH = _os.environ.get("IMD_FUSED_GN_FINISH", "0") == "1"
 FUSED_GN_PROJ = _os.environ.get("IMD_FUSED_GN_PROJ", "1") != "0"
 # (round 6) the skip concatenation of an up block also writes the GroupNorm statistics of its output: norm1 of the resnet behind it skips its statistics launch (A/B switch)
 FUSED_CONCAT_STATS = _os.environ.get("IMD_FUSED_CONCAT_STATS", "1") != "0"
+# (round 6) a residual that repeats over the batch (the two halves of a CFG batch) is read in place by the K = 320 row-resident projection instead of being repeated first (A/B switch)
+PERIODIC_RES = _os.environ.get("IMD_PERIODIC_RES", "1") != "0"
 # ... on which row-resident kernels (A/B): the prologue costs 6-8 us per launch in the running loop (profiles/r6final_kernel_trace_summary.md) -- less than the 10.3 us
 # gn_apply launch it replaces at the 64x64 level (tile config 12), about what the 5.4 / 4.3 us launches of the 32x32 / 16x16 levels (13 / 14) cost WITH their launch
 # boundary: all levels vs the 64x64 level only measured 593.0 vs 593.0 ms over four pairs (profiles/r6n_*) -> all levels (fewer launches, fewer bytes)
@@ -297,6 +299,13 @@ def conv_gemm(
     p.rowvec_stride = rowvec_stride
     p.res = _opt(res, dt, "res")
     p.res_ld = (N if res_ld is None else res_ld)
+    # a residual with FEWER rows than the output is periodic (row m adds res[m % rows]): one copy of a tensor that is the same for both halves of a
+    # CFG batch.  The K = 320 row-resident projection reads it in place (res_rows); everywhere else it is repeated into a full-size tensor first.
+    res_rows = 0
+    if res is not None and res_ld is None and res.numel() != M * N:
+        res_rows = res.numel() // N
+        if res_rows <= 0 or res_rows * N != res.numel() or M % res_rows:
+            raise L.ImdError(f"conv_gemm: the residual has {res.numel()} elements: neither M x N = {M} x {N} nor a whole divisor of it")
     p.out_scale = out_scale
     p.pad_br_only = int(pad_br_only)
     p.act = act
@@ -323,6 +332,12 @@ def conv_gemm(
         if cfg == -1:
             cfg = 5
     if ln_eps is not None:
+        if res_rows:
+            if K == 320 and res_rows % 128 == 0 and PERIODIC_RES:
+                p.res_rows = res_rows
+            else:
+                res = repeat_batch(res.reshape(res_rows, N), M // res_rows)
+                p.res = _dev(res, dt, "res")
         p.split_k = 1
         L.check(lib.imd_row_linear(C.byref(p), 1, float(ln_eps), _stream()))
         return out
@@ -381,6 +396,12 @@ def conv_gemm(
         split_k = 1 if not splittable else lib.imd_conv_gemm_auto_split(M, N, K, cfg)
     if dkey is not None and len(_CFG_DECISIONS) < 4096:
         _CFG_DECISIONS[dkey] = (cfg, split_k)
+    if res_rows:
+        if cfg == 12 and res_rows % 128 == 0 and PERIODIC_RES:
+            p.res_rows = res_rows
+        else:
+            res = repeat_batch(res.reshape(res_rows, N), M // res_rows)
+            p.res = _dev(res, dt, "res")
     p.split_k = split_k
     if gn_in is not None:
         # Transformer2DModel.norm -> proj_in: inside the projection launch where that launch is a row-resident kernel and x came with its statistics

@@ -340,12 +340,13 @@ class Transformer2D:
         values); from the out-projection on the two halves differ and the block continues on B rows."""
         Bh, H, W, Cc = x_half.shape
         blk = self.transformer_blocks[0]
-        x_full = ops.repeat_batch(x_half)                                  # the transformer's own residual (and the caller's skip tensor)
+        # the two residuals of the block -- the transformer's own and attn1's -- are the same for both halves: ONE copy each, added periodically by the
+        # projections (imd_conv_gemm_params.res_rows; ops.conv_gemm repeats them first wherever the launch cannot)
         h = self.proj_in(x_half, gn_in=(self.norm.weight, self.norm.bias, 1e-6, False, self.groups)).view(Bh, H * W, Cc)
-        h_full = ops.repeat_batch(h)                                       # attn1's block residual, one copy per half
-        h = blk.attn1(h, encoder_hidden_states=None, residual=h_full, layernorm=(blk.norm1, 1e-5), imd_pair_half=True, **cak)
+        r = h
+        h = blk.attn1(h, encoder_hidden_states=None, residual=r, layernorm=(blk.norm1, 1e-5), imd_pair_half=True, **cak)
         h = blk.after_attn1(h, ehs, cak)
-        return self.proj_out(h.view(2 * Bh, H, W, Cc), res=x_full)
+        return self.proj_out(h.view(2 * Bh, H, W, Cc), res=x_half)
 
 
 class ResnetBlock:

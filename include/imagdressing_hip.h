@@ -128,6 +128,11 @@ typedef struct imd_conv_gemm_params {
     float gn_out_eps;
     int gn_out_silu;
     int gn_out_groups;
+    /* PERIODIC residual (ABI v9, the K = 320 row-resident projection -- tile config 12 -- only; any other kernel refuses a non-zero value):
+     * `res` holds res_rows rows and output row m adds res[m % res_rows].  The first hybrid block of a CFG batch, whose block input is the same
+     * for the cond and the uncond rows (one copy kept): attn1's out-projection and Transformer2DModel.proj_out add it to both halves without a
+     * materialised torch.cat([x, x]).  Needs res_rows % 128 == 0 and M % res_rows == 0; 0 = one residual row per output row. */
+    int res_rows;
 } imd_conv_gemm_params;
 #define IMD_SPLITK_COUNTERS 16384
 

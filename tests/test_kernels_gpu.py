@@ -1,6 +1,7 @@
 """Per-kernel parity of the HIP path (through the C ABI) against plain fp32 torch references of the
 same op, on seeded inputs.  Tolerance: the north-star bar, atol 1e-2 on O(1) outputs computed in
 bf16 with fp32 accumulation (plus a relative term for large-magnitude GEMM outputs)."""
+import ctypes
 import math
 
 import pytest
@@ -1271,6 +1272,48 @@ def test_concat_that_also_writes_the_groupnorm_statistics(ops, dt, monkeypatch, 
     monkeypatch.setattr(ops, "FUSED_CONCAT_STATS", False)
     off = ops.concat_channels(a, b, c, gn_stats_groups=32)
     assert getattr(off, "_imd_gn_stats", None) is None and torch.equal(off, plain)
+
+
+@DTS
+@pytest.mark.parametrize("M,N,K,rows", [(2048, 320, 320, 1024), (1024, 320, 320, 256), (512, 640, 640, 256), (1024, 320, 320, 64), (768, 192, 320, 256)])
+def test_residual_that_repeats_over_the_batch(ops, dt, monkeypatch, M, N, K, rows):
+    """A residual with fewer rows than the output is periodic (row m adds res[m % rows]: one copy of the block input for both halves of a CFG batch,
+    imd_conv_gemm_params.res_rows).  The K = 320 row-resident projection reads it in place; every other launch gets it repeated first -- bit-identical
+    to handing in the repeated tensor either way, and to the switch being off."""
+    x, w, b = dev(rnd(1, M, K).to(dt)), dev((rnd(2, N, K) * K ** -0.5).to(dt)), dev(rnd(3, N) * 0.1)
+    r = dev(rnd(4, rows, N).to(dt))
+    full = r.repeat(M // rows, 1).contiguous()
+    want = ops.linear(x, w, b, res=full)
+    got = ops.linear(x, w, b, res=r)
+    assert torch.equal(want, got)
+    ref = x.float() @ w.float().t() + b + full.float()
+    assert_close(got, ref, what="linear + periodic residual")
+    monkeypatch.setattr(ops, "PERIODIC_RES", False)
+    assert torch.equal(ops.linear(x, w, b, res=r), want)
+    with pytest.raises(ops.L.ImdError):
+        ops.linear(x, w, b, res=dev(rnd(5, rows - 8, N).to(dt)))          # not a divisor of M
+
+
+def test_periodic_residual_is_refused_where_no_kernel_reads_it(ops):
+    """res_rows on a launch that is not the K = 320 row-resident projection is an error, not a silently ignored field."""
+    L = ops.L
+    M, N, K = 512, 640, 640
+    x, w = dev(rnd(1, M, K).to(torch.bfloat16)), dev(rnd(2, N, K).to(torch.bfloat16))
+    r, out = dev(rnd(3, 256, N).to(torch.bfloat16)), torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    p = L.ConvGemmParams()
+    p.dtype = 0
+    p.x, p.w, p.out, p.res = x.data_ptr(), w.data_ptr(), out.data_ptr(), r.data_ptr()
+    p.M, p.N, p.K, p.Cin, p.taps, p.Hin, p.Win, p.Hout, p.Wout, p.stride = M, N, K, K, 1, 1, M, 1, M, 1
+    p.x_pix_stride, p.res_ld, p.out_ld, p.out_scale, p.split_k = K, N, N, 1.0, 1
+    p.res_rows = 256
+    for cfg in (2, 13):
+        with pytest.raises(L.ImdError, match="res_rows|periodic"):
+            L.check(L.load().imd_conv_gemm(ctypes.byref(p), cfg, None))
+    p.K = p.Cin = p.x_pix_stride = 320
+    p.N = p.res_ld = p.out_ld = 320
+    p.res_rows = 192                                                          # not a multiple of the 128-row block
+    with pytest.raises(L.ImdError, match="res_rows"):
+        L.check(L.load().imd_conv_gemm(ctypes.byref(p), 12, None))
 
 
 @DTS

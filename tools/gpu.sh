@@ -41,7 +41,7 @@ case "$task" in
     DB=$(find gpurun_out/$tag -name "*.db" | head -1)
     python tools/rocprof_summary.py $DB gpurun_out/${tag}_kernel_trace_summary.md
     head -34 gpurun_out/${tag}_kernel_trace_summary.md
-    python tools/rocprof_sequence.py $DB NO_SUCH_KERNEL "" 0 > gpurun_out/${tag}_forward_launches.txt 2>&1 || true
+    python tools/rocprof_sequence.py $DB "" "" 0 > gpurun_out/${tag}_forward_launches.txt 2>&1 || true
     find gpurun_out/$tag -name "*.db" -size +20000k -delete ;;
   ab-env)
     tag="$1"; var="$2"; v1="$3"; v2="$4"; shift 4
