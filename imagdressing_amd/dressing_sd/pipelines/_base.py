@@ -278,59 +278,80 @@ class PipelineBase:
                 ops.ddim_cfg_step(z, eps, x_in.view(2 * B, HW, 8), guidance=float(guidance_scale), a_t=sch.alpha(timesteps[i]),
                                   a_prev=sch.alpha_prev(timesteps[i]), **kw)
 
-        use_graph = (getattr(self, "_step_graph", False) and not multistep and not stochastic and callback is None and trace is None
-                     and len(timesteps) > 2 and (keeps is None or len(set(keeps)) == 1) and ops.ATTN_EVENT_HOOK is None)
-        if use_graph:
-            # HIP-graph replay of the denoising step (opt-in, ``enable_step_graph``): step 0 runs eagerly on the pipeline's side stream
-            # (it also fills the step-invariant K / V caches of the processors), step 1 is CAPTURED (not executed) into a graph whose
-            # only per-step inputs are two device scalars -- the timestep and the six schedule coefficients -- and the graph is then
-            # replayed for steps 1 .. S-1: ~500 kernel launches per step become one hipGraphLaunch (the loop is host-bound at batch 1).
-            steps_n = len(timesteps)
-            t_table = torch.tensor(timesteps, dtype=torch.float32).to(dev)
-            rows = []
-            for i, t in enumerate(timesteps):
-                a_next = (sch.alpha(timesteps[i + 1]) if i < steps_n - 1 else None) if inp is not None else None
-                rows.append(ops.ddim_coefs(sch.alpha(t), sch.alpha_prev(t), a_next))
-            coef_table = torch.tensor(rows, dtype=torch.float32).to(dev)
-            t_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-            coef_dev = torch.zeros(6, dtype=torch.float32, device=dev)
-            side = self.__dict__.get("_graph_stream")
-            if side is None:
-                side = self._graph_stream = torch.cuda.Stream(device=dev)
-            cur = torch.cuda.current_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                t_dev.copy_(t_table[0:1]); coef_dev.copy_(coef_table[0])
-                ddim_step(t_dev, coefs=coef_dev)
-                g = torch.cuda.CUDAGraph()
-                g.capture_begin()
-                try:
+        # The time-embedding chain depends on the timestep only: one pass over the whole schedule here, every forward of the loop picks its row
+        # (unet._Encoder.precompute_time_embeddings; 7 launches per UNet / ControlNet forward gone)
+        encs = [m for m in [self.unet] + ([self.controlnet] if control is not None else []) if hasattr(m, "precompute_time_embeddings")]
+        tables = [e.precompute_time_embeddings(timesteps, dev) for e in encs] if ops.TEMB_TABLE else []
+        if not tables:
+            encs = []
+
+        def run_steps():
+            nonlocal z
+            use_graph = (getattr(self, "_step_graph", False) and not multistep and not stochastic and callback is None and trace is None
+                         and len(timesteps) > 2 and (keeps is None or len(set(keeps)) == 1) and ops.ATTN_EVENT_HOOK is None)
+            if use_graph:
+                # HIP-graph replay of the denoising step (opt-in, ``enable_step_graph``): step 0 runs eagerly on the pipeline's side stream
+                # (it also fills the step-invariant K / V caches of the processors), step 1 is CAPTURED (not executed) into a graph whose
+                # only per-step inputs are two device scalars -- the timestep and the six schedule coefficients -- and the graph is then
+                # replayed for steps 1 .. S-1: ~500 kernel launches per step become one hipGraphLaunch (the loop is host-bound at batch 1).
+                steps_n = len(timesteps)
+                t_table = torch.tensor(timesteps, dtype=torch.float32).to(dev)
+                rows = []
+                for i, t in enumerate(timesteps):
+                    a_next = (sch.alpha(timesteps[i + 1]) if i < steps_n - 1 else None) if inp is not None else None
+                    rows.append(ops.ddim_coefs(sch.alpha(t), sch.alpha_prev(t), a_next))
+                coef_table = torch.tensor(rows, dtype=torch.float32).to(dev)
+                t_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+                coef_dev = torch.zeros(6, dtype=torch.float32, device=dev)
+                side = self.__dict__.get("_graph_stream")
+                if side is None:
+                    side = self._graph_stream = torch.cuda.Stream(device=dev)
+                cur = torch.cuda.current_stream(dev)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    t_dev.copy_(t_table[0:1]); coef_dev.copy_(coef_table[0])
+                    temb_bufs = [torch.empty_like(tab[0:1]) for tab in tables]     # fixed addresses inside the captured step, refreshed like t_dev
+                    for e, buf, tab in zip(encs, temb_bufs, tables):
+                        buf.copy_(tab[0:1])
+                        e.use_time_embedding(buf)
                     ddim_step(t_dev, coefs=coef_dev)
-                finally:
-                    g.capture_end()
-                for i in range(1, steps_n):
-                    t_dev.copy_(t_table[i:i + 1]); coef_dev.copy_(coef_table[i])
-                    g.replay()
-            cur.wait_stream(side)
-            self._last_step_graph = g          # keep the executable graph alive until the next call (replays may still be in flight)
+                    g = torch.cuda.CUDAGraph()
+                    g.capture_begin()
+                    try:
+                        ddim_step(t_dev, coefs=coef_dev)
+                    finally:
+                        g.capture_end()
+                    for i in range(1, steps_n):
+                        t_dev.copy_(t_table[i:i + 1]); coef_dev.copy_(coef_table[i])
+                        for buf, tab in zip(temb_bufs, tables):
+                            buf.copy_(tab[i:i + 1])
+                        g.replay()
+                cur.wait_stream(side)
+                self._last_step_graph = g          # keep the executable graph alive until the next call (replays may still be in flight)
+                return z.view(B, h, w, Cl).permute(0, 3, 1, 2).contiguous()
+            for i, t in enumerate(timesteps):
+                if multistep:
+                    down = mid = None
+                    if control is not None:
+                        down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, ctrl_scale * keeps[i])
+                    eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid, cfg_pair=True)
+                    z = sch.step_guided(eps.view(2 * B, HW, Cl), z, float(guidance_scale))
+                    # emit the next 16-bit UNet input (both CFG halves) from z: the fused step with eps = 0, alpha = 1 is the identity on z
+                    ops.ddim_cfg_step(z, ops.workspace("zero_eps", (2 * B, HW, Cl), torch.float32, dev), x_in.view(2 * B, HW, 8),
+                                      guidance=1.0, a_t=1.0, a_prev=1.0)
+                else:
+                    ddim_step(t, i)
+                if trace is not None:
+                    trace.append(z.clone())
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, z.view(B, h, w, Cl).permute(0, 3, 1, 2))
             return z.view(B, h, w, Cl).permute(0, 3, 1, 2).contiguous()
-        for i, t in enumerate(timesteps):
-            if multistep:
-                down = mid = None
-                if control is not None:
-                    down, mid = self.controlnet.forward_nhwc(x_in, t, ctrl_ehs, ctrl_img, ctrl_scale * keeps[i])
-                eps = self.unet.forward_nhwc(x_in, t, ehs, cak, down, mid, cfg_pair=True)
-                z = sch.step_guided(eps.view(2 * B, HW, Cl), z, float(guidance_scale))
-                # emit the next 16-bit UNet input (both CFG halves) from z: the fused step with eps = 0, alpha = 1 is the identity on z
-                ops.ddim_cfg_step(z, ops.workspace("zero_eps", (2 * B, HW, Cl), torch.float32, dev), x_in.view(2 * B, HW, 8),
-                                  guidance=1.0, a_t=1.0, a_prev=1.0)
-            else:
-                ddim_step(t, i)
-            if trace is not None:
-                trace.append(z.clone())
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, z.view(B, h, w, Cl).permute(0, 3, 1, 2))
-        return z.view(B, h, w, Cl).permute(0, 3, 1, 2).contiguous()
+
+        try:
+            return run_steps()
+        finally:
+            for e in encs:
+                e.clear_time_embeddings()
 
     # ---- shared front / back end ----
     def _cloth_tokens(self, ref_clip_image, ref_clip_hidden_states, device):

@@ -168,6 +168,8 @@ FUSED_GN_PROJ = _os.environ.get("IMD_FUSED_GN_PROJ", "1") != "0"
 FUSED_CONCAT_STATS = _os.environ.get("IMD_FUSED_CONCAT_STATS", "1") != "0"
 # (round 6) a residual that repeats over the batch (the two halves of a CFG batch) is read in place by the K = 320 row-resident projection instead of being repeated first (A/B switch)
 PERIODIC_RES = _os.environ.get("IMD_PERIODIC_RES", "1") != "0"
+# (round 6) the pipelines compute the time embeddings of a whole schedule in one pass before the loop (unet._Encoder.precompute_time_embeddings) (A/B switch)
+TEMB_TABLE = _os.environ.get("IMD_TEMB_TABLE", "1") != "0"
 # ... on which row-resident kernels (A/B): the prologue costs 6-8 us per launch in the running loop (profiles/r6final_kernel_trace_summary.md) -- less than the 10.3 us
 # gn_apply launch it replaces at the 64x64 level (tile config 12), about what the 5.4 / 4.3 us launches of the 32x32 / 16x16 levels (13 / 14) cost WITH their launch
 # boundary: all levels vs the 64x64 level only measured 593.0 vs 593.0 ms over four pairs (profiles/r6n_*) -> all levels (fewer launches, fewer bytes)

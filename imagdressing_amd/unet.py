@@ -349,6 +349,11 @@ class Transformer2D:
         return self.proj_out(h.view(2 * Bh, H, W, Cc), res=x_half)
 
 
+def _temb_stride(temb_all):
+    """batch stride of the time-embedding vector: one row per image, or ONE row for all of them (a precomputed schedule: stride 0)"""
+    return temb_all.shape[1] if temb_all.shape[0] > 1 else 0
+
+
 class ResnetBlock:
     def __init__(self, sd, p, groups, device, temb_slices: list, dtype=bf16):
         self.norm1 = NormParams(sd, f"{p}.norm1", device)
@@ -366,7 +371,7 @@ class ResnetBlock:
     def __call__(self, x, temb_all):
         if ops.FUSED_GN_CONV and x.shape[2] >= 32 and x.shape[1] >= 8:          # (A/B switch: the 64x64 / 32x32 maps, where the halo-patch kernel is the tuned choice)
             a, b = ops.group_norm_coeffs(x, self.norm1.weight, self.norm1.bias, groups=self.groups, eps=1e-5)
-            h = self.conv1(x, rowvec=temb_all, rowvec_stride=temb_all.shape[1], rowvec_off=self.temb_off, gn_stats_groups=self.groups, gn=(a, b, True))
+            h = self.conv1(x, rowvec=temb_all, rowvec_stride=_temb_stride(temb_all), rowvec_off=self.temb_off, gn_stats_groups=self.groups, gn=(a, b, True))
             a, b = ops.group_norm_coeffs(h, self.norm2.weight, self.norm2.bias, groups=self.groups, eps=1e-5)
             sc = x if self.shortcut is None else self.shortcut(x)
             return self.conv2(h, res=sc, gn_stats_groups=self.groups, gn=(a, b, True))
@@ -374,7 +379,7 @@ class ResnetBlock:
         # (gn_stats_groups: where the conv runs on the halo-patch kernel its epilogue also emits the GroupNorm statistics of its
         # output, and the next group_norm of that tensor -- norm2 here, the following block's norm after conv2 -- skips its own pass)
         # (gn_out: where conv1 is K-sliced -- the 16x16 / 8x8 levels -- its finish launch applies norm2 + SiLU itself and the raw conv1 output never exists)
-        h = self.conv1(h, rowvec=temb_all, rowvec_stride=temb_all.shape[1], rowvec_off=self.temb_off, gn_stats_groups=self.groups,
+        h = self.conv1(h, rowvec=temb_all, rowvec_stride=_temb_stride(temb_all), rowvec_off=self.temb_off, gn_stats_groups=self.groups,
                        gn_out=(self.norm2.weight, self.norm2.bias, 1e-5, True, self.groups))
         if not getattr(h, "_imd_gn_applied", False):
             h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, groups=self.groups, eps=1e-5, silu=True)
@@ -446,15 +451,48 @@ class _Encoder(PretrainedMixin):
 
     # ---- shared forward pieces ----
     def _time_embed(self, timestep, B, device):
+        """-> [B, sum(Cout)] fp32, or [1, sum(Cout)] when one row serves the whole batch (a schedule precomputed by
+        :meth:`precompute_time_embeddings`; the resnets then read it with a batch stride of 0)."""
+        fixed = self.__dict__.get("_temb_fixed")
+        if fixed is not None:
+            return fixed
+        tab = self.__dict__.get("_temb_table")
+        if tab is not None and not torch.is_tensor(timestep):
+            i = tab[1].get(float(timestep))
+            if i is not None:
+                return tab[0][i:i + 1]
         if not torch.is_tensor(timestep):
             t = torch.full((B,), float(timestep), dtype=torch.float32, device=device)
         else:
             t = timestep.to(device=device, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        return self._time_embed_rows(t)
+
+    def _time_embed_rows(self, t):
+        """t [R] fp32 timesteps -> [R, sum(Cout)] fp32: sinusoid -> linear_1 -> SiLU -> linear_2 (-> SiLU) -> every resnet's time_emb_proj as one GEMM
+        (diffusers UNet2DConditionModel.forward: time_proj, time_embedding; ResnetBlock2D.time_emb_proj(nonlinearity(temb)))."""
         e = ops.f32_to_16(ops.timestep_embedding(t, self.time_lin1.in_features), self.dtype)
         e = ops.linear(e, self.time_lin1.weight, self.time_lin1.bias, act=ops.ACT_SILU)
         # every consumer applies SiLU first (ResnetBlock2D.time_emb_proj(nonlinearity(temb))): store silu(temb)
         e = ops.linear(e, self.time_lin2.weight, self.time_lin2.bias, act=ops.ACT_SILU)
-        return ops.linear(e, self.temb_proj.weight, self.temb_proj.bias, out_f32=True)     # [B, sum(Cout)] fp32
+        return ops.linear(e, self.temb_proj.weight, self.temb_proj.bias, out_f32=True)     # [R, sum(Cout)] fp32
+
+    # The chain above depends on the timestep only -- not on the latent -- and the denoising loop knows its whole schedule up front (round 6): the
+    # pipeline runs it ONCE over all timesteps of a call (R = 50 rows instead of 50 passes of one row: 7 launches, ~65 us, per UNet forward) and every
+    # forward of the loop picks its row.  All images of a batch share the timestep, so the row is handed to the resnets as a [1, C] vector with batch
+    # stride 0.  Engine-internal: a forward outside a pipeline call computes the chain as before.
+    def precompute_time_embeddings(self, timesteps, device):
+        ts = [float(t) for t in timesteps]
+        table = self._time_embed_rows(torch.tensor(ts, dtype=torch.float32).to(device))
+        self._temb_table = (table, {k: i for i, k in enumerate(ts)})
+        return table
+
+    def use_time_embedding(self, row):
+        """``row`` [1, sum(Cout)] fp32 (a fixed buffer the caller refreshes per step: HIP-graph replay) or None."""
+        self._temb_fixed = row
+
+    def clear_time_embeddings(self):
+        self._temb_table = None
+        self._temb_fixed = None
 
     def _run_down(self, x, temb_all, ehs, cak, pair_skip=None, pair_attn_done=False):
         """``pair_skip``: the caller has already run conv_in and the first resnet on ONE half of a CFG batch whose halves are identical

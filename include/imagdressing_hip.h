@@ -68,7 +68,7 @@ typedef struct imd_conv_gemm_params {
     int out_ld, res_ld;
     const float* bias;   /* [N] or NULL */
     const float* rowvec; /* per-batch vector [B][rowvec_stride] added to every pixel of batch b, or NULL */
-    int rowvec_stride;
+    int rowvec_stride;   /* floats between the vectors of consecutive batch entries; 0 = ONE vector for the whole batch (a shared timestep) */
     const uint16_t* res; /* residual [M, res_ld] or NULL */
     float out_scale;     /* applied after bias/rowvec, before the residual add */
     int act;             /* IMD_ACT_* */

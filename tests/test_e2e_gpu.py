@@ -92,6 +92,38 @@ def test_unet_forward_small_with_garment(small_pair):
 
 
 @torch.no_grad()
+def test_time_embeddings_of_a_whole_schedule_at_once(small_pair):
+    """The pipelines run the time-embedding chain once over all timesteps of a call and every forward picks its row, handed to the resnets as ONE
+    vector for the whole batch (rowvec_stride 0): the rows equal the per-forward chain's (same GEMMs on more rows: fp32 summation order only), a
+    forward with the table equals a forward without it, and the table is gone after clear_time_embeddings()."""
+    p = small_pair
+    unet = p["e_unet"]
+    ts = [981, 721, 481, 1]
+    table = unet.precompute_time_embeddings(ts, "cuda")
+    try:
+        assert table.shape[0] == len(ts) and table.dtype == torch.float32
+        for i, t in enumerate(ts):
+            row = unet._time_embed_rows(torch.full((2,), float(t), dtype=torch.float32, device="cuda"))
+            assert torch.equal(row[0], row[1])
+            st = err_stats(table[i:i + 1], row[:1])
+            assert st["rel_rms"] < 2e-3 and st["max_abs"] < 2e-2 * max(st["ref_std"], 1e-3), (t, st)
+            got = unet._time_embed(t, 2, "cuda")
+            assert got.shape[0] == 1 and got.data_ptr() == table[i:i + 1].data_ptr()
+        x = g(1, 2, 4, 16, 16).cuda(); ehs = g(2, 2, 77, 64, scale=0.5).cuda()
+        with_table = unet(x, 481, ehs)[0]
+    finally:
+        unet.clear_time_embeddings()
+    assert unet._time_embed(481, 2, "cuda").shape[0] == 2
+    without = unet(x, 481, ehs)[0]
+    st = err_stats(with_table, without); record(f"unet_forward_small_schedule_time_embeddings[{p['dtype']}]", st)
+    assert st["rel_rms"] < 2e-3 and st["max_abs"] < 1e-2, st
+    ref = p["o_unet"](x.cpu(), 481, ehs.cpu())
+    st = err_stats(with_table, ref)
+    bar = BARS[p["dtype"]]
+    assert st["max_abs"] < bar["max_abs"] and st["rel_rms"] < bar["rel_rms"], st
+
+
+@torch.no_grad()
 def test_pipeline_small_20_steps(small_pair):
     """B=2 images sharing a garment == 2 independent runs of the reference loop (oracle)."""
     from imagdressing_amd.dressing_sd.pipelines.IMAGDressing_v1_pipeline import IMAGDressing_v1
