@@ -63,15 +63,19 @@ def only_linear(args, shapes, dt):
     table = doc.get("shapes", {})
     log = []
     for key, t in sorted(shapes.items(), key=lambda kv: -kv[1]["count"] * kv[1]["M"] * kv[1]["N"] * kv[1]["K"]):
-        if t["taps"] != 1 or key not in table:
+        tkey = key if key in table else key.split("|")[0]       # (3x3 shapes are traced with their map, the table may hold the plain key)
+        if tkey not in table or (t["taps"] != 1 and not args.keys) or (args.keys and tkey not in args.keys.split(";") and key not in args.keys.split(";")):
             continue
-        ent = table[key]
+        ent = table[tkey]
         shipped = (ent["cfg"], ent["split"]) if t["any_splittable"] else (ent["cfg_nosplit"], 1)
         cands = {}
         for rep in range(2):
             if args.cands:          # a focused re-time: the shipped choice against the named tile configs (un-split, and at the shipped K split)
                 cc = [int(c) for c in args.cands.split(",")]
                 others = [(c, 1) for c in cc] + ([(c, shipped[1]) for c in cc] if shipped[1] > 1 else [])
+                if args.splits and t["any_splittable"]:
+                    others += [(c, sp) for c in cc for sp in (int(x) for x in args.splits.split(",")) if sp > 1 and (t["K"] + 63) // 64 // sp >= 4]
+                others = list(dict.fromkeys(others))
                 if t["K"] % 64 or t["K"] < args.min_k:
                     continue
             else:
@@ -121,6 +125,8 @@ def main():
                     help="re-time only the 3x3 stride-1 convolutions (candidates 0, 4, 5) and merge into the shipped table")
     ap.add_argument("--cands", default="", help="with --only-linear: comma list of tile configs to time against the shipped choice (e.g. 25,27)")
     ap.add_argument("--min-k", type=int, default=0, help="with --cands: only shapes with K >= this")
+    ap.add_argument("--splits", default="", help="with --cands: also time every candidate at these K splits (comma list, e.g. 2,4) where the shape is splittable")
+    ap.add_argument("--keys", default="", help="with --only-linear --cands: re-time exactly these table keys (';'-separated; 3x3 keys allowed)")
     ap.add_argument("--only-linear", action="store_true",
                     help="re-time only the plain linear layers (taps = 1) with the shipped choice against the unsplit candidates 0, 4, 9, 10, 11 and "
                          "the round-2 kernels 12..16; an entry changes only when the winner is > 3 %% faster than the shipped choice")

@@ -70,6 +70,14 @@ case "$task" in
       d=$(timeout 300 python tools/configs.py --config 5 --steps 10 2>/dev/null | ms)
       echo "table=$T  512x512_ms_per_bench_step=$a  512x640=$b  configs2_ms_per_ddim_step=$c  configs4_ms_per_ddim_step=$d"
     done; done | tee gpurun_out/${tag}_table_ab.txt ;;
+  insitu)
+    # in-situ A/B of tile configs: every further argument is one run's list of forced table entries, e.g. "2048,1280,2560,1,1,0=32:2 8192,640,1920,1,1,0=32:1"
+    # (tools/insitu_conv.py --force: HIP events around each imd_conv_gemm launch inside the running sampling loop, per shape key)
+    tag="$1"; shift; i=0
+    { timeout 300 python tools/insitu_conv.py --top 400 2>/dev/null | sed "s/^/base /"
+      for f in "$@"; do i=$((i+1)); timeout 300 python tools/insitu_conv.py --top 400 --force $f 2>/dev/null | sed "s/^/run$i /"; done
+    } > gpurun_out/${tag}_insitu.txt
+    grep -c . gpurun_out/${tag}_insitu.txt ;;
   retune)
     tag="$1"; shift
     T=imagdressing_amd/gemm_tuning.json
