@@ -459,6 +459,9 @@ int imd_attn_dpk(int D) { return (D + 15) / 16 * 16; }
 int imd_attn_dpv(int D) { return (D + 31) / 32 * 32; }
 
 int g_attn_xcd = 1;
+#ifdef IMD_ATTN_SWEEP
+int g_attn_v80 = 0, g_attn_v160 = 0;      // (sweep builds: template parameters of the generic kernel at head dims 80 / 160, imd_set_tuning(3 / 4, .))
+#endif
 
 int imd_attention_dup_supported(int H, int N, int D) { return (D == 40 && N >= 512 && H > 0) ? 1 : 0; }
 
@@ -514,8 +517,32 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
             if (qw40 == 1 && p.N >= 512) return h ? launch_attn<true, 40, 2, 2, 1, true, 0>(p, s) : launch_attn<false, 40, 2, 2, 1, true, 0>(p, s);
             return h ? launch_attn<true, 40, 1, 3, 1, true>(p, s) : launch_attn<false, 40, 1, 3, 1, true>(p, s);
         case 64: return h ? launch_attn<true, 64, 1, 2>(p, s) : launch_attn<false, 64, 1, 2>(p, s);
-        case 80: return h ? launch_attn<true, 80, 1, 2>(p, s) : launch_attn<false, 80, 1, 2>(p, s);
-        case 160: return h ? launch_attn<true, 160, 1, 1>(p, s) : launch_attn<false, 160, 1, 1>(p, s);
+        case 80:
+#ifdef IMD_ATTN_SWEEP
+            switch (g_attn_v80) {
+                case 1: return h ? launch_attn<true, 80, 1, 2, 2, false, 0>(p, s) : launch_attn<false, 80, 1, 2, 2, false, 0>(p, s);      // (the default before round 6)
+                case 2: return h ? launch_attn<true, 80, 1, 3, 1, false, 0>(p, s) : launch_attn<false, 80, 1, 3, 1, false, 0>(p, s);
+                case 3: return h ? launch_attn<true, 80, 1, 3, 1, false, 2>(p, s) : launch_attn<false, 80, 1, 3, 1, false, 2>(p, s);
+                case 4: return h ? launch_attn<true, 80, 2, 1, 2, false, 0>(p, s) : launch_attn<false, 80, 2, 1, 2, false, 0>(p, s);
+                case 5: return h ? launch_attn<true, 80, 2, 1, 2, false, 3>(p, s) : launch_attn<false, 80, 2, 1, 2, false, 3>(p, s);
+                case 6: return h ? launch_attn<true, 80, 2, 1, 1, false, 3>(p, s) : launch_attn<false, 80, 2, 1, 1, false, 3>(p, s);
+                case 7: return h ? launch_attn<true, 80, 1, 2, 1, false, 2>(p, s) : launch_attn<false, 80, 1, 2, 1, false, 2>(p, s);
+                default: break;
+            }
+#endif
+            // (round 6: the next tile's loads issued unconditionally, SCHED = 2 -- 53.6 -> 51.7 us at the 32x32 level, 29.0 -> 27.5 us at the 16x16 level,
+            // tools/attn_generic_sweep.py, profiles/r6ab_*; two query blocks per wave lose 60 % here)
+            return h ? launch_attn<true, 80, 1, 2, 2, false, 2>(p, s) : launch_attn<false, 80, 1, 2, 2, false, 2>(p, s);
+        case 160:
+#ifdef IMD_ATTN_SWEEP
+            switch (g_attn_v160) {
+                case 1: return h ? launch_attn<true, 160, 1, 1, 2, false, 0>(p, s) : launch_attn<false, 160, 1, 1, 2, false, 0>(p, s);      // (the default before round 6)
+                case 2: return h ? launch_attn<true, 160, 1, 1, 1, false, 2>(p, s) : launch_attn<false, 160, 1, 1, 1, false, 2>(p, s);
+                case 3: return h ? launch_attn<true, 160, 1, 2, 1, false, 0>(p, s) : launch_attn<false, 160, 1, 2, 1, false, 0>(p, s);
+                default: break;
+            }
+#endif
+            return h ? launch_attn<true, 160, 1, 1, 2, false, 2>(p, s) : launch_attn<false, 160, 1, 1, 2, false, 2>(p, s);
         default: return imd_set_error("attention: unsupported head dim %d (supported: 40, 64, 80, 160)", p.D);
     }
 }

@@ -147,6 +147,10 @@ int imd_set_tuning(int knob, int value) {
 #endif
             IMD_REQUIRE((value & ~2047) == 0, "set_tuning: knob 2 has bits 0..10 only (got %d)", value);
             g_gemm_flags = value; return 0;
+#ifdef IMD_ATTN_SWEEP
+        case 3: g_attn_v80 = value; return 0;
+        case 4: g_attn_v160 = value; return 0;
+#endif
         default: return imd_set_error("set_tuning: unknown knob %d", knob);
     }
 }

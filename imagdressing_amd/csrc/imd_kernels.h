@@ -68,6 +68,9 @@ int imd_launch_attn_quantize_fp8(const bf16_t* src, unsigned char* dst, int kind
                                  float pad_val, int dtype, hipStream_t s);   // attention_d40.hip: software-pipelined level-0 kernel
 extern int g_attn_qw40;
 extern int g_attn_xcd;
+#ifdef IMD_ATTN_SWEEP
+extern int g_attn_v80, g_attn_v160;
+#endif
 extern int g_gemm_flags;
 int imd_attn_dpk(int D);
 int imd_attn_dpv(int D);
