@@ -1294,6 +1294,21 @@ def test_residual_that_repeats_over_the_batch(ops, dt, monkeypatch, M, N, K, row
         ops.linear(x, w, b, res=dev(rnd(5, rows - 8, N).to(dt)))          # not a divisor of M
 
 
+@DTS
+@pytest.mark.parametrize("M,N,K,rows", [(1024, 320, 320, 256), (512, 320, 320, 128), (512, 640, 640, 256)])
+def test_periodic_residual_behind_the_layernorm_prologue(ops, dt, M, N, K, rows):
+    """LayerNorm prologue + residual is the STAGED epilogue of the row-resident kernel: its periodic form (K = 320: the residual base shifted per
+    workgroup; other K: repeated first by ops.conv_gemm) equals the repeated residual bit for bit, and the fp32 reference within the 16-bit bar."""
+    x, w, b = dev(rnd(1, M, K).to(dt)), dev((rnd(2, N, K) * K ** -0.5).to(dt)), dev(rnd(3, N) * 0.1)
+    r = dev(rnd(4, rows, N).to(dt))
+    full = r.repeat(M // rows, 1).contiguous()
+    want = ops.linear(x, w, b, res=full, ln_eps=1e-5)
+    got = ops.linear(x, w, b, res=r, ln_eps=1e-5)
+    assert torch.equal(want, got)
+    xn = torch.nn.functional.layer_norm(x.float(), (K,), eps=1e-5)
+    assert_close(got, xn @ w.float().t() + b + full.float(), what="LayerNorm + linear + periodic residual")
+
+
 def test_periodic_residual_is_refused_where_no_kernel_reads_it(ops):
     """res_rows on a launch that is not the K = 320 row-resident projection is an error, not a silently ignored field."""
     L = ops.L
