@@ -254,6 +254,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 
             use_col_pre = true;
         }
     }
+    // GroupNorm statistics of the output tile (gn_stats_out; round 6: also from this kernel -- conv_in, the stride-2 downsampler of the 64x64 level, the
+    // projections that land here): conv_patch.hip's scheme.  A thread keeps the same 8 channels for every row it emits (COLS_FIXED), so it accumulates
+    // (sum, sum of squares) of the values it STORES (rounded to the element type) for the at most two groups those channels belong to; the launcher only
+    // asks when the tile's rows lie in one image (H W % BM == 0) and a group has >= 8 channels.
+    const bool want_stats = COLS_FIXED && p.gn_stats_out != nullptr && slab == nullptr && !colmajor;
+    const int st_cpg = want_stats ? p.N / p.gn_stats_groups : 1;
+    const int st_n = n0 + (tid % CPR) * 8;
+    const int st_split = min(8, (st_n / st_cpg + 1) * st_cpg - st_n);       // channels [0, split) of the chunk -> its first group
+    float st[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int wr = 0; wr < WAVES_M; ++wr) {
         if (wave / WAVES_N == wr) {
@@ -282,10 +291,46 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (WAVES_M * WAVES_N == 4) ? 
                 slab_store8(slab, (size_t)m * p.N + n, v0, v1, n + 8 <= p.N, p.splitk_counters != nullptr);
             } else {
                 float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                epilogue8<F16>(p, v, m, n, (n + 8 <= p.N) ? 8 : 4, HWo, use_col_pre, col_pre0, col_pre1);
+                const int nv = (n + 8 <= p.N) ? 8 : 4;
+                epilogue8<F16>(p, v, m, n, nv, HWo, use_col_pre, col_pre0, col_pre1);
+                if (want_stats) {               // v now holds the final values (bias / vector / residual / activation applied)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (e < nv) {
+                            const float r = E::tof(E::fromf(v[e]));
+                            if (e < st_split) { st[0] += r; st[1] += r * r; }
+                            else { st[2] += r; st[3] += r * r; }
+                        }
+                    }
+                }
             }
         }
         if (wr + 1 < WAVES_M) __syncthreads();
+    }
+    if (want_stats) {
+        __syncthreads();                        // the fp32 tile in LDS is dead: its head takes the NT x 4 partials
+        float* red = reinterpret_cast<float*>(smem);
+        *reinterpret_cast<float4*>(red + tid * 4) = make_float4(st[0], st[1], st[2], st[3]);
+        __syncthreads();
+        const int G = p.gn_stats_groups;
+        if (tid < G) {                          // fixed summation order: column chunk, then row lane (deterministic)
+            const int g = tid;
+            float S = 0.f, Q = 0.f;
+            for (int j = 0; j < CPR; ++j) {
+                const int nj = n0 + 8 * j;
+                if (nj >= p.N) break;
+                const int gj = nj / st_cpg;
+                if (gj == g || gj + 1 == g) {
+                    const int o = (gj == g) ? 0 : 2;
+                    for (int rl = 0; rl < NT / CPR; ++rl) { S += red[(j + CPR * rl) * 4 + o]; Q += red[(j + CPR * rl) * 4 + o + 1]; }
+                }
+            }
+            const int parts_m = HWo / BM;
+            const int nparts = parts_m * n_tiles;
+            const int part = (tile_m % parts_m) * n_tiles + tile_n;
+            float* dst = p.gn_stats_out + (((size_t)(m0 / HWo) * nparts + part) * G + g) * 2;
+            dst[0] = S; dst[1] = Q;
+        }
     }
     // K slices summed in-kernel by the tile's last-arriving workgroup (see splitk_last_arrival) instead of by a second launch
     if (slab != nullptr && p.splitk_counters != nullptr) {
@@ -581,12 +626,22 @@ int imd_gemm_pick_order(const ConvGemmParams& p, int n_tiles) {
 int imd_conv_gemm_stats_parts_of(const ConvGemmParams& p_in, int cfg) {
     ConvGemmParams p = p_in;
     if (p.split_k < 1) p.split_k = 1;
+    if (cfg < 0) cfg = imd_conv_gemm_choose_cfg(p.M, p.N);       // (as the launcher resolves it)
     if (p.split_k > 1) {
         if (cfg == 21 || cfg == 22 || cfg == 23 || cfg == 24 || cfg == 29 || (cfg >= 17 && cfg <= 20) || (cfg >= 25 && cfg <= 28) || (cfg >= 30 && cfg <= 32)) p.splitk_counters = nullptr;      // (these always finish with the second launch)
         return splitk_stats_parts_of(p);
     }
     if (cfg == 22 || cfg == 23) return imd_conv_patch3_stats_parts_of(p, cfg == 23 ? 8 : 4);
-    return (cfg == 5 || cfg == 29) ? imd_conv_patch_stats_parts_of(p) : 0;
+    if (cfg == 5 || cfg == 29) return imd_conv_patch_stats_parts_of(p);
+    // the register-staged tiles whose epilogue threads keep their column block (conv_gemm_kernel's statistics epilogue): whole tiles of one image only
+    if (cfg == 0 || cfg == 1 || cfg == 2 || cfg == 3 || cfg == 4 || cfg == 7) {
+        int bm = 0, bn = 0;
+        tile_dims(cfg, &bm, &bn);
+        const int HW = p.Hout * p.Wout, G = p.gn_stats_groups;
+        if (p.out_f32 || p.mode != OUT_ROWMAJOR || p.act == ACT_GEGLU || G <= 0 || G > 64 || p.N % G || (p.N / G) < 8 || (p.N % 4) || HW <= 0 || HW % bm || p.M % HW) return 0;
+        return (HW / bm) * ((p.N + bn - 1) / bn);
+    }
+    return 0;
 }
 
 // can tile config `cfg` normalise its input rows as p.gn_in_* asks (the row-resident projections only)?
@@ -687,7 +742,7 @@ int imd_launch_conv_gemm(const ConvGemmParams& p_in, int cfg, hipStream_t s) {
     // ERROR -- a launch that silently skipped the write would leave the next imd_groupnorm(nparts > 0) reading uninitialised memory, and
     // gn_stats_groups = 0 / fewer than 8 channels per group would divide by zero / straddle more than two groups in the kernel
     if (p.gn_stats_out != nullptr && imd_conv_gemm_stats_parts_of(p, cfg) == 0)
-        return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 / 22 / 23 / 29 without K slices or any K-sliced launch with a separate finish, a row-major 16-bit "
+        return imd_set_error("conv_gemm: gn_stats_out needs tile config 5 / 22 / 23 / 29 or a register-staged tile (0..4, 7) with H W %% its rows == 0, without K slices, or any K-sliced launch with a separate finish; a row-major 16-bit "
                              "output and 1 <= groups <= 64 with N %% groups == 0 and N / groups >= 8 (got cfg=%d split_k=%d groups=%d N=%d); ask "
                              "imd_conv_gemm_stats_parts() first", cfg, p.split_k, p.gn_stats_groups, p.N);
     // GroupNorm of the output inside the finish launch (ABI v9): only a K-sliced problem with a separate finish has one -- anything else is an

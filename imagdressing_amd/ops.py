@@ -168,6 +168,11 @@ FUSED_GN_PROJ = _os.environ.get("IMD_FUSED_GN_PROJ", "1") != "0"
 FUSED_CONCAT_STATS = _os.environ.get("IMD_FUSED_CONCAT_STATS", "1") != "0"
 # (round 6) a residual that repeats over the batch (the two halves of a CFG batch) is read in place by the K = 320 row-resident projection instead of being repeated first (A/B switch)
 PERIODIC_RES = _os.environ.get("IMD_PERIODIC_RES", "1") != "0"
+# (round 6) GroupNorm statistics from the epilogue of the register-staged tile kernel (conv_in, the 64x64-level downsampler, proj_out of the 8x8 level: three
+# statistics launches per forward).  OPT-IN: correct and tested, but measured neutral at batch 4 (twelve interleaved pairs: 563.95 vs 563.92 ms) and 0.36 % SLOWER at
+# batch 1 (six pairs: 342.7 vs 344.0 ms) -- the reduction at the end of the tile kernel sits on the critical path of launches that do not fill the chip
+# (profiles/r6ah_*)
+GENERIC_GN_STATS = _os.environ.get("IMD_GENERIC_GN_STATS", "0") == "1"
 # (round 6) the pipelines compute the time embeddings of a whole schedule in one pass before the loop (unet._Encoder.precompute_time_embeddings) (A/B switch)
 TEMB_TABLE = _os.environ.get("IMD_TEMB_TABLE", "1") != "0"
 # ... on which row-resident kernels (A/B): the prologue costs 6-8 us per launch in the running loop (profiles/r6final_kernel_trace_summary.md) -- less than the 10.3 us
@@ -443,7 +448,10 @@ def conv_gemm(
         p.gn_out_gamma = p.gn_out_beta = None
         p.gn_out_groups = 0
     stats = None
-    if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and (cfg in (5, 22, 23, 29) or split_k > 1):
+    # (round 6: the register-staged tiles 0..4 / 7 write them too -- conv_in, the stride-2 downsampler of the 64x64 level -- wherever a tile's rows lie in one image;
+    #  GENERIC_GN_STATS is the A/B switch of that addition)
+    if gn_stats_groups and FUSED_GN_STATS and heads is None and not out_f32 and act != ACT_GEGLU and \
+            (cfg in (5, 22, 23, 29) or split_k > 1 or (GENERIC_GN_STATS and cfg in (-1, 0, 1, 2, 3, 4, 7))):
         p.gn_stats_groups = gn_stats_groups
         nparts = lib.imd_conv_gemm_stats_parts(C.byref(p), cfg)       # halo-patch epilogue (un-split) or the finish launch of the K slices
         if nparts > 0:

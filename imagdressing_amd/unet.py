@@ -316,7 +316,8 @@ class Transformer2D:
         h = self.proj_in(x, gn_in=(self.norm.weight, self.norm.bias, 1e-6, False, self.groups)).view(B, H * W, Cc)
         for blk in self.transformer_blocks:
             h = blk(h, ehs, cak)
-        return self.proj_out(h.view(B, H, W, Cc), res=x)
+        # (gn_stats_groups: the next resnet's norm1 finds its statistics on the result where the projection's kernel writes them -- the 8x8 level)
+        return self.proj_out(h.view(B, H, W, Cc), res=x, gn_stats_groups=self.groups)
 
     # ---- first hybrid block of a CFG batch (round 6) ----
     def pair_half_ok(self, x_half, cak) -> bool:
@@ -603,7 +604,7 @@ class UNet2DConditionModel(_Encoder):
         ehs = encoder_hidden_states
         temb_all = self._time_embed(timestep, B, x.device)
         if cfg_pair and B % 2 == 0 and ops.CFG_PAIR_DEDUP:
-            h0 = self.conv_in(x[:B // 2])
+            h0 = self.conv_in(x[:B // 2], gn_stats_groups=self.cfg["norm_num_groups"])
             blk0 = self.down_blocks[0]
             r0 = blk0.resnets[0](h0, temb_all)
             # the first transformer's input is still identical for the two halves: norm / proj_in / norm1 / q-k-v / the self-attention
@@ -614,7 +615,7 @@ class UNet2DConditionModel(_Encoder):
             else:
                 h, skips = self._run_down(ops.repeat_batch(r0), temb_all, ehs, cak, pair_skip=h0)
         else:
-            h = self.conv_in(x)
+            h = self.conv_in(x, gn_stats_groups=self.cfg["norm_num_groups"])          # (feeds the first resnet's norm1)
             h, skips = self._run_down(h, temb_all, ehs, cak)
         h = self._run_mid(h, temb_all, ehs, cak)
         if mid_block_additional_residual is not None:

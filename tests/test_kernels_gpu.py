@@ -784,16 +784,63 @@ def test_splitk_finish_groupnorm_statistics(ops, cfg, B, H, W, Cin, Cout, G, spl
     own = ops.group_norm(plain_out, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=True)
     assert_close(fused, own.float(), atol=2 * TOL[dt], what="finish statistics vs own pass")
     with pytest.raises(ops.L.ImdError):           # a request the launch cannot honour is an error at the C ABI, not a silent skip
-        p = dict(kw, cfg=0, split_k=1)
+        p = dict(kw, cfg=6, split_k=1)
         t = ops.conv2d_nhwc(xd, dev(pack_conv(w)), dev(b), **p)
-        import ctypes
         q = ops.L.ConvGemmParams()
         q.x, q.w, q.out = xd.data_ptr(), dev(pack_conv(w)).data_ptr(), t.data_ptr()
         q.M, q.N, q.K, q.Cin, q.taps = B * Ho * Wo, Cout, 9 * Cin, Cin, 9
         q.Hin, q.Win, q.Hout, q.Wout, q.stride, q.x_pix_stride, q.out_ld, q.res_ld = H, W, Ho, Wo, stride, Cin, Cout, Cout
         q.out_scale, q.split_k, q.dtype = 1.0, 1, (1 if dt == torch.float16 else 0)
         q.gn_stats_out, q.gn_stats_groups = part.data_ptr(), G
-        ops.L.check(ops.L.load().imd_conv_gemm(ctypes.byref(q), 0, 0))
+        ops.L.check(ops.L.load().imd_conv_gemm(ctypes.byref(q), 6, 0))          # (the 64 x 320 tiles have no statistics epilogue)
+
+
+@pytest.mark.parametrize("cfg,B,H,W,Cin,Cout,G,stride,taps", [
+    (0, 2, 64, 64, 8, 320, 32, 1, 9),          # conv_in: 128 x 128 tiles, 32 tiles per image x 3 column tiles (the last one half empty)
+    (-1, 2, 64, 64, 8, 320, 32, 1, 9),         # ... with the tile config left to the library
+    (2, 2, 32, 32, 64, 320, 32, 2, 9),         # the stride-2 downsampler of the 64x64 level: 64 x 64 tiles, 10 channels per group (chunks straddle groups)
+    (2, 4, 8, 8, 128, 1280, 32, 1, 1),         # Transformer2DModel.proj_out of the 8x8 level (+ residual): one 64-row tile per image
+    (1, 2, 16, 16, 64, 192, 8, 1, 9),          # 128 x 64 tiles, 24 channels per group
+    (4, 1, 32, 32, 32, 96, 8, 1, 9),           # 128 x 128 x 32 tiles, 12 channels per group, one ragged column tile
+    (3, 2, 16, 16, 32, 128, 16, 1, 9), (7, 2, 16, 16, 32, 128, 16, 1, 1),
+])
+@DTS
+def test_register_staged_tiles_groupnorm_statistics(ops, monkeypatch, cfg, B, H, W, Cin, Cout, G, stride, taps, dt):
+    """The register-staged tile kernel (tile configs 0..4, 7) writes the GroupNorm statistics of the tensor it stores where a tile's rows lie in one
+    image (round 6: conv_in, the 64x64-level downsampler, proj_out of the 8x8 level): same tensor as without, partials = the stored tensor's moments,
+    group_norm on them == group_norm with its own statistics pass within the 16-bit bar; silently absent where a tile would span images."""
+    monkeypatch.setattr(ops, "GENERIC_GN_STATS", True)          # (opt-in: measured neutral / slower end to end, see ops.py)
+    x = rnd(1, B, H, W, Cin).to(dt)
+    w = rnd(2, Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5).to(dt) if taps == 9 else rnd(2, Cout, Cin, scale=Cin ** -0.5).to(dt)
+    wd = dev(pack_conv(w)) if taps == 9 else dev(w)
+    Ho, Wo = H // stride, W // stride
+    b = rnd(3, Cout); res = rnd(5, B, Ho, Wo, Cout).to(dt)
+    gamma = 1.0 + 0.2 * rnd(6, Cout); beta = 0.2 * rnd(7, Cout)
+    kw = dict(res=dev(res), cfg=cfg, split_k=1, stride=stride, taps=taps)
+    out = ops.conv2d_nhwc(dev(x), wd, dev(b), gn_stats_groups=G, **kw)
+    plain = ops.conv2d_nhwc(dev(x), wd, dev(b), **kw)
+    assert torch.equal(out, plain)
+    st = getattr(out, "_imd_gn_stats", None)
+    assert st is not None and st[2] == G and tuple(st[0].shape) == (B, st[1], G, 2)
+    folded = st[0].double().sum(1).cpu()
+    o = out.double().cpu().permute(0, 3, 1, 2).reshape(B, G, -1)
+    n = o.shape[-1]
+    assert torch.allclose(folded[..., 0] / n, o.mean(-1), atol=1e-4), "group means"
+    assert torch.allclose(folded[..., 1] / n, (o * o).mean(-1), rtol=1e-4, atol=1e-4), "group second moments"
+    fused = ops.group_norm(out, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=True)
+    own = ops.group_norm(plain, dev(gamma), dev(beta), groups=G, eps=1e-5, silu=True)
+    assert_close(fused, own.float(), atol=2 * TOL[dt], what="epilogue statistics vs own pass")
+    monkeypatch.setattr(ops, "GENERIC_GN_STATS", False)
+    assert getattr(ops.conv2d_nhwc(dev(x), wd, dev(b), gn_stats_groups=G, **kw), "_imd_gn_stats", None) is None
+
+
+@DTS
+def test_register_staged_tiles_statistics_absent_when_a_tile_spans_images(ops, monkeypatch, dt):
+    monkeypatch.setattr(ops, "GENERIC_GN_STATS", True)
+    x = dev(rnd(1, 4, 8, 8, 64).to(dt)); w = dev(rnd(2, 128, 64, scale=0.125).to(dt))
+    out = ops.conv2d_nhwc(x, w, None, taps=1, cfg=0, split_k=1, gn_stats_groups=16)          # 64 pixels per image, 128-row tiles
+    assert getattr(out, "_imd_gn_stats", None) is None
+    assert_close(out, x.float() @ w.float().t(), what="conv")
 
 
 @pytest.mark.parametrize("cfg,B,H,W,Cin,Cout,G,split", [
