@@ -63,11 +63,15 @@ if __name__ == "__main__":
     ap.add_argument("--N", type=int, default=4096, help="tokens of the level-0 shape (6912 = the 768x576 configuration)")
     ap.add_argument("--zero", action="store_true", help="all-zero Q/K/V: same instruction stream, far fewer toggling bits (clock / power probe)")
     ap.add_argument("--default-only", action="store_true", help="level-0 shape with the library's default knobs only (PMC passes)")
+    ap.add_argument("--level", default="", help="D,N: only this level's shape with the library's default knobs (PMC passes of the generic kernel: 80,1024 / 160,256)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     cases = [(40, 4096, 4096, 4, 2, 1), (40, 4096, 4096, 4, 1, 1), (40, 4096, 4096, 4, 2, 0), (40, 4096, 4096, 4, 1, 0)]
     if a.variants:
         cases = [(40, a.N, a.N, 4, int(v), 1) for v in a.variants.split(",")]
+    elif a.level:
+        d_, n_ = (int(v) for v in a.level.split(","))
+        cases = [(d_, n_, n_, 4, None, 1)]
     elif a.default_only:
         cases = [(40, 4096, 4096, 4, None, 1)]
     elif not a.only_l0:
