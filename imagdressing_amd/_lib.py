@@ -67,7 +67,7 @@ class AttnParams(_Sized):
         ("out_ld", C.c_int), ("dtype", C.c_int), ("flags", C.c_int), ("causal", C.c_int), ("k_pad_one", C.c_int),
         ("proj_w", C.c_void_p), ("proj_b", C.c_void_p), ("proj_res", C.c_void_p), ("proj_out", C.c_void_p),
         ("proj_res_ld", C.c_int), ("proj_out_ld", C.c_int), ("proj_counters", C.c_void_p),
-        ("out_dup", C.c_void_p),
+        ("out_dup", C.c_void_p), ("phase2_out", C.c_void_p), ("phase2_rows", C.c_int),
     ]
 
 
@@ -108,6 +108,7 @@ SYMBOLS = {
     "imd_conv_gemm_auto_split": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "imd_attention": (C.c_int, [C.POINTER(AttnParams), C.c_void_p]),
     "imd_attention_dup_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "imd_attention_phase_split_supported": (C.c_int, [C.c_int]),
     "imd_attention_fp8": (C.c_int, [C.POINTER(AttnParams), C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "imd_attn_quantize_fp8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_long, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "imd_set_tuning": (C.c_int, [C.c_int, C.c_int]),

@@ -224,12 +224,14 @@ def _fp8_kv(kv, cache: bool):
 def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, self_attn: bool,
                      kv1=None, kv1_bdiv: int = 1, kv2=None, kv2_bdiv: int = 1, scale2: Optional[torch.Tensor] = None,
                      wo: torch.Tensor, bo: Optional[torch.Tensor], residual: Optional[torch.Tensor],
-                     q_ln: Optional[tuple] = None, pair_half: bool = False) -> torch.Tensor:
+                     q_ln: Optional[tuple] = None, pair_half: bool = False, phase2_rows: int = 0) -> torch.Tensor:
     """x [B, N, C] bf16 -> out-projected attention output [B, N, C] (+ residual).  ``q_ln`` = (W_q', b_q', eps): ``x`` is the
     block's UN-normalised hidden state and LayerNorm runs inside the Q projection (cross-attention, C = 320 only).
     ``pair_half`` (self-attention with a garment key set only): ``x`` holds the B cond rows of a CFG batch whose uncond rows have
     bit-identical hidden states; the result has 2B rows -- [0, B) the hybrid output, [B, 2B) the plain self-attention output of
-    the same rows (the attention launch stores its first phase twice, ``imd_attn_params.out_dup``) -- and ``residual`` has 2B rows, or B (the same block input for both halves, one copy)."""
+    the same rows (the attention launch stores its first phase twice, ``imd_attn_params.out_dup``) -- and ``residual`` has 2B rows, or B (the same block input for both halves, one copy).
+    ``phase2_rows`` = R: exactly the rows [0, R) carry the second key set (``scale2`` non-zero): ops.attention may run their two softmaxes as separate
+    workgroups (``imd_attn_params.phase2_rows``; bit-identical)."""
     B, N, Cc = x.shape
     D = Cc // heads
     dpk, dpv = ops.attn_padded_dims(D)
@@ -281,7 +283,7 @@ def _fused_attention(x: torch.Tensor, heads: int, *, wq_or_qkv: torch.Tensor, se
         # (the residual may hold B or 2B rows: B = one copy for both halves, added periodically by the projection -- ops.conv_gemm)
         res2 = None if residual is None else residual.reshape(-1, Cc)
         return ops.linear(o.view(2 * B * N, Cc), wo, bo, res=res2).view(2 * B, N, Cc)
-    ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True, **kw)
+    ops.attention(q, kv1[0], kv1[1], o, B=B, H=heads, N=N, D=D, L1=kv1[2], L1P=kv1[3], kv1_bdiv=kv1_bdiv, k_pad_one=True, phase2_rows=phase2_rows if kw else 0, **kw)
     res2 = None if residual is None else residual.view(B * N, Cc)
     return ops.linear(o.view(B * N, Cc), wo, bo, res=res2).view(B, N, Cc)
 
@@ -461,8 +463,11 @@ class RefSAttnProcessor2_0(nn.Module, _FusedBase, _RefMixin):
             s2 = self._branch_weights(x.shape[0] * (2 if imd_pair_half else 1), sa_batch_mask, x.device)      # (pair_half: the kernel reads the cond rows' entries [0, B))
         if imd_pair_half and (kv2 is None or imd_residual is None or shape4 is not None):
             raise ValueError("imd_pair_half needs sa_hidden_states, the block residual and token-major hidden states (engine-internal)")
+        # (sa_pair_layout: the pipeline's mask is "garment on for rows [0, B/2), off for the rest" -- lets the 32x32 / 16x16 / 8x8 levels split the two softmaxes
+        #  of the cond rows over workgroups)
+        pr = x.shape[0] // 2 if (kwargs.get("sa_pair_layout") and sa_batch_mask is not None and kv2 is not None and not imd_pair_half and x.shape[0] % 2 == 0) else 0
         out = _fused_attention(x, attn.heads, wq_or_qkv=wqkv, self_attn=True, kv2=kv2, kv2_bdiv=bdiv2,
-                               scale2=s2, wo=wo, bo=bo, residual=imd_residual, q_ln=q_ln, pair_half=bool(imd_pair_half))
+                               scale2=s2, wo=wo, bo=bo, residual=imd_residual, q_ln=q_ln, pair_half=bool(imd_pair_half), phase2_rows=pr)
         return self._finish(attn, out, imd_residual is not None, hidden_states, shape4, ln_fused=imd_layernorm is not None)
 
 

@@ -109,6 +109,11 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
         b = (int)((w / gx) % gz);
         h = (int)(w / (gx * gz));
     }
+    // phase-split launch (imd_attn_params.phase2_rows): batch entries >= B run the SECOND softmax of row b - B only (fp32 result to phase2_out, added to the
+    // first by a follow-up elementwise launch), entries < B the first one only
+    const bool split = p.phase2_rows > 0;
+    const bool second_only = split && b >= p.B;
+    if (second_only) b -= p.B;
     const int q0 = (wx * 4 + wave) * (QW * 32);
 
     // V^T row D (the all-ones row) of both LDS buffers, written once and never restaged
@@ -137,12 +142,12 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     const bool causal = p.causal != 0;
     float w2 = 0.f;
     if (p.k2 != nullptr && p.scale2 != nullptr) w2 = p.scale2[b];
-    const int nph = (w2 != 0.f) ? 2 : 1;
+    const int nph = split ? (second_only ? 2 : 1) : ((w2 != 0.f) ? 2 : 1);
 
     f32x16 o[QW][C::NDT];
     float m_run[QW], l_run[QW];
 
-    for (int ph = 0; ph < nph; ++ph) {
+    for (int ph = second_only ? 1 : 0; ph < nph; ++ph) {
 #pragma unroll
         for (int qb = 0; qb < QW; ++qb) {
             m_run[qb] = OFFS ? 0.f : -INFINITY; l_run[qb] = 0.f;       // OFFS: m_run is m_ref (starts at 0)
@@ -413,6 +418,10 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = o[qb][dt][4 * j + e] * inv;
+                    if (second_only) {          // w2 * O2 / l2 in fp32: the follow-up launch adds it to the stored first phase
+                        *reinterpret_cast<float4*>(p.phase2_out + ((size_t)b * p.N + q) * (p.H * D) + h * D + dd) = make_float4(v[0], v[1], v[2], v[3]);
+                        continue;
+                    }
                     if (ph == 1) {
                         const uint2 prev = *reinterpret_cast<const uint2*>(orow + dd);
                         v[0] += E::lo(prev.x); v[1] += E::hi(prev.x); v[2] += E::lo(prev.y); v[3] += E::hi(prev.y);
@@ -423,6 +432,22 @@ __global__ __launch_bounds__(256, MINW) void attn_kernel(const AttnParams p) {
     }
 }
 
+// out[r, c] = round16(out[r, c] + add[r, c]) over `rows` rows of C channels (4 per thread): the phase-split launch's addition of the second softmax
+template <bool F16>
+__global__ __launch_bounds__(256) void attn_phase_add_kernel(bf16_t* out, int out_ld, const float* __restrict__ add, int C, long rows) {
+    using E = El<F16>;
+    const int vpr = C / 4;
+    const long total = rows * vpr;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long r = i / vpr;
+        const int c = (int)(i - r * vpr) * 4;
+        const float4 a = *reinterpret_cast<const float4*>(add + r * C + c);
+        uint2* dst = reinterpret_cast<uint2*>(out + r * out_ld + c);
+        const uint2 prev = *dst;
+        *dst = make_uint2(E::pack2(a.x + E::lo(prev.x), a.y + E::hi(prev.x)), E::pack2(a.z + E::lo(prev.y), a.w + E::hi(prev.y)));
+    }
+}
+
 template <bool F16, int D, int QW, int MINW, int KB = 2, bool SPEC = false, int SCHED = 0>
 int launch_attn(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
@@ -430,9 +455,15 @@ int launch_attn(const AttnParams& p, hipStream_t s) {
     auto kern = attn_kernel<F16, D, QW, MINW, KB, SPEC, SCHED>;
     if (int rc_attr = imd_lds_attr(reinterpret_cast<const void*>(kern), lds, "attention")) return rc_attr;
     const int rows = 4 * QW * 32;
-    dim3 grid((p.N + rows - 1) / rows, p.H, p.B);
+    dim3 grid((p.N + rows - 1) / rows, p.H, p.B + (p.phase2_rows > 0 ? p.phase2_rows : 0));
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-    return imd_check_launch("attention");
+    int rc = imd_check_launch("attention");
+    if (rc || p.phase2_rows <= 0) return rc;
+    // the second launch of the phase-split form: out[r] = round(out[r] + phase2_out[r]) for the rows with a second softmax
+    const long vecs = (long)p.phase2_rows * p.N * (p.H * D / 4);
+    const int blocks = (int)((vecs + 255) / 256 < 4096 ? (vecs + 255) / 256 : 4096);
+    hipLaunchKernelGGL(attn_phase_add_kernel<F16>, dim3(blocks), dim3(256), 0, s, p.out, p.out_ld, p.phase2_out, p.H * D, (long)p.phase2_rows * p.N);
+    return imd_check_launch("attention (phase add)");
 }
 
 }  // namespace
@@ -464,6 +495,7 @@ int g_attn_v80 = 0, g_attn_v160 = 0;      // (sweep builds: template parameters 
 #endif
 
 int imd_attention_dup_supported(int H, int N, int D) { return (D == 40 && N >= 512 && H > 0) ? 1 : 0; }
+int imd_attention_phase_split_supported(int D) { return (D == 64 || D == 80 || D == 160) ? 1 : 0; }
 
 int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     AttnParams p = p_in;
@@ -489,6 +521,15 @@ int imd_launch_attention(const AttnParams& p_in, hipStream_t s) {
     if (p.dtype != IMD_DTYPE_BF16 && p.dtype != IMD_DTYPE_F16) return imd_set_error("attention: unknown dtype %d", p.dtype);
     if (p.causal && (p.k2 != nullptr || p.L1 != p.N)) return imd_set_error("attention: the causal mask needs a single key set with L1 == N");
     const bool h = p.dtype == IMD_DTYPE_F16;
+    if ((p.phase2_rows != 0) != (p.phase2_out != nullptr)) return imd_set_error("attention: phase2_rows and phase2_out go together");
+    if (p.phase2_rows != 0) {           // phase-split launch (ABI v9): the generic kernel only
+        if (!imd_attention_phase_split_supported(p.D) || p.k2 == nullptr || p.scale2 == nullptr || p.causal || p.proj_w != nullptr || p.out_dup != nullptr ||
+            p.phase2_rows < 0 || p.phase2_rows > p.B || (p.out_ld % 4) || p.B + p.phase2_rows > 65535)
+            return imd_set_error("attention: phase2_rows needs head dim 64 / 80 / 160, a second key set with scale2, 0 < rows <= B, no causal mask / fused out-projection / "
+                                 "out_dup (got D=%d rows=%d B=%d)", p.D, p.phase2_rows, p.B);
+        if ((reinterpret_cast<uintptr_t>(p.phase2_out) & 15) || (reinterpret_cast<uintptr_t>(p.out) & 7))
+            return imd_set_error("attention: phase2_out must be 16-byte aligned (out 8-byte)");
+    }
     if (p.out_dup != nullptr) {         // duplicated first-phase output (ABI v9): the static-ring d = 40 kernel only
         if (!imd_attention_dup_supported(p.H, p.N, p.D) || !p.k_pad_one || p.causal || p.proj_w != nullptr)
             return imd_set_error("attention: out_dup needs head dim 40, N >= 512, k_pad_one, no causal mask and no fused out-projection (got D=%d N=%d k_pad_one=%d)", p.D, p.N, p.k_pad_one);

@@ -4,6 +4,7 @@ and non-contiguous views raise -- there is no eager fallback.
 """
 from __future__ import annotations
 
+import functools
 import ctypes as C
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -618,9 +619,22 @@ def attention_dup_supported(H: int, N: int, D: int) -> bool:
     return bool(L.load().imd_attention_dup_supported(H, N, D))
 
 
+# (round 6) phase-split launch of the hybrid attention at the 32x32 / 16x16 / 8x8 levels (imd_attn_params.phase2_rows; A/B switch)
+ATTN_PHASE_SPLIT = _os.environ.get("IMD_ATTN_PHASE_SPLIT", "1") != "0"
+ATTN_PHASE_SPLIT_MAX_N = int(_os.environ.get("IMD_ATTN_PHASE_SPLIT_MAX_N", "512"))      # (kernel alone, tools/attn_bench.py --phase-split: N = 256: 29.6 -> 19.8 us, N = 64: 15.5 -> 11.3 us, N = 1024: 60.3 -> 64.0 us)
+
+
+@functools.lru_cache(maxsize=None)
+def attention_phase_split_supported(D: int) -> bool:
+    return bool(L.load().imd_attention_phase_split_supported(D))
+
+
 def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=None, scale2=None,
-              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False, k_pad_one=False, proj=None, out_dup=None):
+              L2=0, L2P=0, kv2_bdiv=1, out_ld=None, causal=False, k_pad_one=False, proj=None, out_dup=None, phase2_rows=0):
     """``k_pad_one``: k1 (and k2) came from :func:`k_buffer`, i.e. their pad column D holds 1.0 (see the header).
+    ``phase2_rows`` = R: the caller guarantees that exactly the rows [0, R) have a non-zero ``scale2`` (the cond half of a CFG batch); where the library
+    takes it (:func:`attention_phase_split_supported`, switch ``ATTN_PHASE_SPLIT``) the two softmaxes of those rows run as separate workgroups of ONE launch
+    and a follow-up elementwise launch adds them -- bit-identical to the one-workgroup form, half as long per workgroup.  Ignored elsewhere.
     ``out_dup`` [B, N, C]: also receives softmax(Q K1^T) V1 of every batch entry (the paired uncond rows of a CFG batch's first hybrid
     block, :func:`attention_dup_supported`).
     ``proj`` = (w [C, C], bias [C] fp32 | None, residual [B, N, C] | None, proj_out [B, N, C]): the out-projection fused into the
@@ -644,6 +658,10 @@ def attention(q, k1, v1t, out, *, B, H, N, D, L1, L1P, kv1_bdiv=1, k2=None, v2t=
         if out_dup.numel() != out.numel():
             raise L.ImdError("attention: out_dup must have the shape of out")
         p.out_dup = _dev(out_dup, dt, "out_dup")
+    if phase2_rows and ATTN_PHASE_SPLIT and k2 is not None and scale2 is not None and proj is None and out_dup is None and not causal \
+            and 0 < phase2_rows <= B and attention_phase_split_supported(D) and N <= ATTN_PHASE_SPLIT_MAX_N:
+        p.phase2_rows = int(phase2_rows)
+        p.phase2_out = workspace("attn_phase2", (phase2_rows * N * H * D,), torch.float32, q.device).data_ptr()
     ret = out
     if proj is not None:
         pw, pb, pres, pout = proj

@@ -173,6 +173,16 @@ typedef struct imd_attn_params {
      * cond rows (`out`) and the uncond rows (`out_dup`), bit-identical to a 2B-row launch (RefSAttnProcessor2_0 with and without
      * sa_hidden_states on the same hidden states, attention_processor.py:589-612). */
     uint16_t* out_dup;
+    /* Phase-split launch of the hybrid attention (ABI v9; imd_attention_phase_split_supported(): head dims 64 / 80 / 160, k2 given, no causal mask):
+     * the two softmaxes of a row with a second key set are independent until their results are added, and at the 32x32 / 16x16 / 8x8 levels a
+     * launch has too few workgroups to hide one row's 2 x L / 64 sequential key tiles.  With phase2_rows = R > 0 the rows [0, R) are the ones
+     * whose scale2 is non-zero (the cond half of a CFG batch) and the grid grows to B + R batch entries: entry b < B runs the FIRST softmax of
+     * row b only and stores it as a row without a second key set would; entry B + r runs the SECOND softmax of row r and stores
+     * scale2[r] * softmax(Q K2^T) V2 as fp32 to phase2_out[r, :, :] ([R, N, H * D]); a second, elementwise launch then writes
+     * out[r] = round(out[r] + phase2_out[r]) -- the same arithmetic as the one-workgroup form (first result rounded to the element type,
+     * second added in fp32, rounded once): bit-identical, with every workgroup half as long and 1.5x as many of them. */
+    float* phase2_out;   /* NULL: off */
+    int phase2_rows;
 } imd_attn_params;
 
 /* Fused feed-forward of a transformer block on the 64x64 level (ff_fused.hip), C = 320, inner = 1280:
@@ -297,6 +307,8 @@ int imd_row_linear_gn_in_supported(const imd_conv_gemm_params* p, int cfg);
 int imd_conv_gemm_gn_out_supported(const imd_conv_gemm_params* p);
 /* 1 iff imd_attention accepts imd_attn_params.out_dup for this head count / query count / head dim (with k_pad_one = 1) */
 int imd_attention_dup_supported(int H, int N, int D);
+/* 1 iff imd_attention runs phase2_rows / phase2_out at this head dim (the generic kernel: 64, 80, 160) */
+int imd_attention_phase_split_supported(int D);
 /* padded head dims of the Q/K rows (dpk) and V^T rows (dpv) for head dim D */
 int imd_attn_padded_dims(int D, int* dpk, int* dpv);
 /* performance knobs (results are identical for every accepted setting up to fp32 summation order).  knob 0: head-dim-40 attention

@@ -1379,6 +1379,62 @@ def test_periodic_residual_is_refused_where_no_kernel_reads_it(ops):
 
 
 @DTS
+@pytest.mark.parametrize("D,B,R,N,L2", [(80, 8, 4, 1024, 1024), (80, 4, 2, 320, 257), (160, 8, 4, 256, 256), (160, 2, 1, 64, 64), (160, 6, 3, 80, 200), (64, 4, 4, 128, 77), (80, 3, 1, 96, 96)])
+def test_hybrid_attention_phase_split_is_bit_identical(ops, dt, monkeypatch, D, B, R, N, L2):
+    """imd_attn_params.phase2_rows: the rows [0, R) carry the second key set; their two softmaxes run as separate workgroups of one launch and a follow-up
+    launch adds the fp32 second result to the stored first one -- the arithmetic of the one-workgroup form, so the output is BIT-IDENTICAL; also against the
+    fp32 reference of the hybrid attention (attention_processor.py:589-612)."""
+    H = 4
+    dpk, dpv = ops.attn_padded_dims(D)
+    def r(seed, *s): return rnd(seed, *s)
+    q = torch.zeros(B, H, N, dpk); q[..., :D] = r(1, B, H, N, D) * (D ** -0.5 * math.log2(math.e))
+    k = torch.zeros(B, H, N, dpk); k[..., :D] = r(2, B, H, N, D)
+    v = r(3, B, H, N, D)
+    k2 = torch.zeros(1, H, L2, dpk); k2[..., :D] = r(4, 1, H, L2, D)
+    v2 = r(5, 1, H, L2, D)
+    def vt_of(vv, L):
+        t = torch.zeros(vv.shape[0], H, dpv, ops.pad64(L)); t[:, :, :D, :L] = vv.transpose(-1, -2); return t
+    qd, kd, vtd = dev(q.to(dt)), dev(k.to(dt)), dev(vt_of(v, N).to(dt))
+    if dpk > D:
+        kd[..., D] = 1.0
+    k2d, v2td = dev(k2.to(dt)), dev(vt_of(v2, L2).to(dt))
+    if dpk > D:
+        k2d[..., D] = 1.0
+    s2 = dev(torch.cat([torch.full((R,), 0.75), torch.zeros(B - R)]))
+    kw = dict(B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=k2d, v2t=v2td, scale2=s2, L2=L2, L2P=ops.pad64(L2), kv2_bdiv=B, k_pad_one=True)
+    one = torch.empty(B, N, H * D, dtype=dt, device="cuda")
+    two = torch.empty_like(one)
+    ops.attention(qd, kd, vtd, one, **kw)
+    ops.attention(qd, kd, vtd, two, phase2_rows=R, **kw)
+    assert torch.equal(one, two)
+    monkeypatch.setattr(ops, "ATTN_PHASE_SPLIT", False)
+    off = torch.empty_like(one)
+    ops.attention(qd, kd, vtd, off, phase2_rows=R, **kw)
+    assert torch.equal(one, off)
+    qf, kf, vf = q.to(dt).float()[..., :D] / math.log2(math.e), k.to(dt).float()[..., :D], v.to(dt).float()
+    a1 = torch.softmax(qf @ kf.transpose(-1, -2), -1) @ vf
+    a2 = torch.softmax(qf @ k2.to(dt).float()[..., :D].transpose(-1, -2), -1) @ v2.to(dt).float()
+    ref = a1 + s2.cpu().view(B, 1, 1, 1) * a2
+    assert_close(two, ref.permute(0, 2, 1, 3).reshape(B, N, H * D), what="hybrid attention")
+
+
+def test_phase_split_is_refused_where_no_kernel_runs_it(ops):
+    L = ops.L
+    p = L.AttnParams()
+    t = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
+    f = torch.zeros(4096, dtype=torch.float32, device="cuda")
+    p.q = p.k1 = p.v1t = p.k2 = p.v2t = p.out = t.data_ptr()
+    p.scale2 = f.data_ptr()
+    p.B, p.H, p.N, p.D, p.L1, p.L1P, p.kv1_bdiv, p.L2, p.L2P, p.kv2_bdiv, p.out_ld = 2, 1, 64, 40, 64, 64, 1, 64, 64, 2, 40
+    p.phase2_rows, p.phase2_out = 1, f.data_ptr()
+    with pytest.raises(L.ImdError, match="phase2_rows"):
+        L.check(L.load().imd_attention(ctypes.byref(p), None))           # head dim 40: the d = 40 kernel has no phase-split form
+    p.D, p.out_ld, p.phase2_out = 80, 80, None
+    with pytest.raises(L.ImdError, match="go together"):
+        L.check(L.load().imd_attention(ctypes.byref(p), None))
+
+
+@DTS
 def test_add_concat_cast(ops, dt):
     a = rnd(1, 2, 50, 320).to(dt); b = rnd(2, 2, 50, 640).to(dt); c = rnd(3, 2, 50, 640).to(dt)
     assert_close(ops.add(dev(b), dev(c), 0.5), b.float() + 0.5 * c.float(), what="add")

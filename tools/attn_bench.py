@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from imagdressing_amd import ops
 
-def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False, fp8=False):
+def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False, fp8=False, phase_split=False):
     H = 8
     B = 2 * Bimg
     dpk, dpv = ops.attn_padded_dims(D)
@@ -32,7 +32,8 @@ def run(D, N, M, Bimg, iters, dt, qw=None, xcd=1, zero=False, fp8=False):
         if fp8:
             ops.attention_fp8(q8, k8, v8, out, B=B, H=H, N=N, L1=N, L1P=ops.pad64(N), k2=kr8, v2t=vr8, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B)
             return
-        ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B, k_pad_one=True)
+        ops.attention(q, k, vt, out, B=B, H=H, N=N, D=D, L1=N, L1P=ops.pad64(N), k2=kr, v2t=vr, scale2=s2, L2=M, L2P=ops.pad64(M), kv2_bdiv=B, k_pad_one=True,
+                      phase2_rows=Bimg if phase_split else 0)
     for _ in range(3): go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -63,6 +64,7 @@ if __name__ == "__main__":
     ap.add_argument("--N", type=int, default=4096, help="tokens of the level-0 shape (6912 = the 768x576 configuration)")
     ap.add_argument("--zero", action="store_true", help="all-zero Q/K/V: same instruction stream, far fewer toggling bits (clock / power probe)")
     ap.add_argument("--default-only", action="store_true", help="level-0 shape with the library's default knobs only (PMC passes)")
+    ap.add_argument("--phase-split", action="store_true", help="with --level: A/B the phase-split launch (imd_attn_params.phase2_rows) against the one-workgroup form")
     ap.add_argument("--level", default="", help="D,N: only this level's shape with the library's default knobs (PMC passes of the generic kernel: 80,1024 / 160,256)")
     a = ap.parse_args()
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -79,6 +81,8 @@ if __name__ == "__main__":
     for rep in range(2):          # interleaved repeats: within-run A/B
         for D, N, M, Bi, qw, xcd in cases:
             print(json.dumps(dict(run(D, N, M, Bi, a.iters, dt, qw, xcd, a.zero), zero=a.zero)), flush=True)
+            if a.phase_split and a.level:
+                print(json.dumps(dict(run(D, N, M, Bi, a.iters, dt, qw, xcd, a.zero, phase_split=True), phase_split=True)), flush=True)
         if a.fp8:
             print(json.dumps(dict(run(40, a.N, a.N, 4, a.iters, dt, None, 1, a.zero, fp8=True), fp8=True)), flush=True)
     ops.L.load().imd_set_tuning(0, 10); ops.L.load().imd_set_tuning(1, 1)
